@@ -1,0 +1,128 @@
+/*
+ * mdhip.h -- C ABI of libmdhip.so: the MI355X (gfx950) force + velocity-Verlet + thermostat
+ * path behind MolecularDynamics.jl's Parameters / SimulationState / Potential / evaluate /
+ * run_simulation! surface.
+ *
+ * Every entry point is extern "C", takes plain integers, doubles and pointers, returns an
+ * int status (0 = ok, non-zero = error; text via md_last_error) and never lets a C++
+ * exception cross the boundary.  Host arrays are borrowed for the duration of one call;
+ * device memory is owned by the handle.  A handle is bound to one GPU and is not
+ * re-entrant.  Citations are  file:line  into the reference (edwinb-ai/MolecularDynamics.jl
+ * v0.7).
+ *
+ * Host array layout: column-major d x N, i.e. particle i's component c at a[i*d + c]
+ * (a Julia Matrix{Float64}(d, N); the Julia wrapper packs its Vector{MVector{d}} into one).
+ * Particle indices are 0-based at this boundary.
+ */
+#ifndef MDHIP_H
+#define MDHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct md_ctx md_ctx;
+
+/* Potential kinds for md_set_potential.  params layout per kind:
+ *   MD_POT_LJ            {epsilon, sigma, r_cut}   src/potentials.jl:41-64,66-77,160-164
+ *                         (sigma is unused by the pair term, as in the reference: the pair
+ *                          sigma comes from the two diameters)
+ *   MD_POT_PSEUDOHS      {lambda}                  src/potentials.jl:1-29
+ *   MD_POT_POLYDISPERSE  {r_cut, non_additivity}   README.md:89-145 (user potential example)
+ *   MD_POT_CUSTOM        set through md_set_potential_source (hiprtc)                      */
+enum { MD_POT_LJ = 0, MD_POT_PSEUDOHS = 1, MD_POT_POLYDISPERSE = 2, MD_POT_CUSTOM = 100 };
+
+/* Ensemble kinds for md_run: src/types.jl:34-51, src/integrate.jl:40-53 */
+enum { MD_NVE = 0, MD_NVT = 1 };
+
+/* Replaces CellListMap.ParticleSystem(xpositions, unitcell, cutoff, ...) +
+ * SimulationState's device-side half: src/initialization.jl:100-107, src/types.jl:15-32.
+ * box is the d x d unit cell (column-major); only diagonal (orthorhombic) cells are
+ * accepted in this version.  list_cutoff is CellListMap's cutoff (independent
+ * of the potential's own r_cut).  device_id < 0 means "current device".               */
+int md_create(int dim, int64_t n_particles, const double *box, double list_cutoff, int device_id, md_ctx **out);
+int md_destroy(md_ctx *ctx);
+
+/* Last error text for a handle; with ctx == NULL, the last error of a failed md_create. */
+const char *md_last_error(md_ctx *ctx);
+
+/* Replaces compile-time dispatch of evaluate(pot::P, r, s1, s2): src/pairwise.jl:28-31,
+ * src/types.jl:1-6. */
+int md_set_potential(md_ctx *ctx, int kind, const double *params, int nparams);
+
+/* User-defined potential compiled at run time (hiprtc).  hip_src must define
+ *   __device__ void <entry_name>(double r, double sigma1, double sigma2,
+ *                                const double* params, double* u, double* f);
+ * returning the pair energy u and f = -dU/dr exactly like the reference's evaluate
+ * contract (README.md:86-88,116-117). */
+int md_set_potential_source(md_ctx *ctx, const char *hip_src, const char *entry_name, const double *params,
+                            int nparams);
+
+/* Verlet-list skin.  skin = 0 rebuilds the linked cells every step exactly as
+ * CellListMap.map_pairwise! does (src/simulation.jl:100-104); skin > 0 reuses a neighbour
+ * list built with cutoff+skin until some particle has moved skin/2 -- the accepted pair set
+ * of every step is unchanged (pairs are still filtered by d^2 <= list_cutoff^2).          */
+int md_set_skin(md_ctx *ctx, double skin);
+
+/* State transfer; any pointer may be NULL (= leave that array as it is on the device).
+ * x, v, f: d x N doubles; images: d x N int32; diameters: N doubles.
+ * Mirrors the fields of SimulationState / EnergyAndForces: src/types.jl:15-32,53-57.
+ * Forces persist across md_run calls and start at whatever was uploaded. */
+int md_upload(md_ctx *ctx, const double *x, const double *v, const double *f, const int32_t *images,
+              const double *diameters);
+int md_download(md_ctx *ctx, double *x, double *v, double *f, int32_t *images);
+
+/* reset_output! + CellListMap.map_pairwise!(energy_and_forces!, system):
+ * src/pairwise.jl:6-15,26-39; src/simulation.jl:99-104.  Leaves forces on the device,
+ * returns the potential energy U and the virial W = sum_pairs f_ij . r_ij.              */
+int md_compute_forces(md_ctx *ctx, double *energy, double *virial);
+
+/* The accepted pair set of the current positions: every unordered pair {i,j} with
+ * d^2 <= list_cutoff^2, as (min,max) 0-based int32 pairs, unsorted.  count receives the
+ * number found; at most cap pairs are written.  (CellListMap's pair enumeration, exposed
+ * for the bit-exact neighbour-index parity check.)                                       */
+int md_neighbor_pairs(md_ctx *ctx, int32_t *pairs, int64_t cap, int64_t *count);
+
+/* The step loop of run_simulation!: src/simulation.jl:88-108 --
+ *   integrate_half! (src/integrate.jl:8-21, wrap src/boundary.jl:7-17) -> reset_output! ->
+ *   map_pairwise! -> integrate_second_half! (src/integrate.jl:28-38) -> ensemble_step!
+ *   (src/integrate.jl:40-53; bussi! src/thermostat.jl:20-48).
+ * Runs nsteps steps device-resident.  For MD_NVT, ktemp[s], r1[s], r2[s] (s = 0..nsteps-1)
+ * are the target temperature ens.ktemp(step+1) and the two random draws of bussi! for step
+ * s (r1 = randn, r2 = sum_noises(nf-1), src/thermostat.jl:1-18,32-33): the RNG stays on the
+ * host.  nf is SimulationState.nf = d*(N-1) (src/initialization.jl:124).
+ * If uwk != NULL it receives {U, W, K} of the LAST step (potential energy, virial, kinetic
+ * energy after the thermostat) -- what the thermo line of src/simulation.jl:118-136 needs. */
+int md_run(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, double tau, double nf, const double *ktemp,
+           const double *r1, const double *r2, double *uwk);
+
+/* compute_kinetic: src/thermostat.jl:50-60 */
+int md_kinetic(md_ctx *ctx, double *kinetic);
+
+/* Velocity rescale v *= s (the last loop of bussi!, src/thermostat.jl:43-45), exposed for
+ * host-driven thermostats. */
+int md_scale_velocities(md_ctx *ctx, double s);
+
+/* Instrumentation (not part of the reference surface). */
+typedef struct {
+    int64_t steps;          /* steps integrated since create */
+    int64_t rebuilds;       /* cell/neighbour-list rebuilds */
+    int64_t violations;     /* rebuilds triggered by the displacement check (not scheduled) */
+    int64_t n_ghost;        /* periodic ghost copies in the last build */
+    int64_t max_neighbors;  /* neighbour-list row capacity */
+    double avg_neighbors;   /* mean list length of the last build (candidates/particle) */
+    int64_t force_launches; /* force-kernel launches timed since md_profile(ctx,1) */
+    double force_ms;        /* their summed duration, HIP events on the handle's stream */
+} md_stats;
+int md_profile(md_ctx *ctx, int enable);
+int md_get_stats(md_ctx *ctx, md_stats *out);
+
+/* Library build info: returns e.g. "mdhip 0.1 gfx950". */
+const char *md_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDHIP_H */

@@ -1,0 +1,80 @@
+"""ctypes binding of csrc/libmdhip.so -- the C ABI declared in include/mdhip.h.
+
+There is NO CPU fallback: if the shared library is missing, or no HIP device is present when
+a handle is created, this raises.  Nothing here imports the oracle.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "csrc", "libmdhip.so")
+
+MD_POT_LJ, MD_POT_PSEUDOHS, MD_POT_POLYDISPERSE, MD_POT_CUSTOM = 0, 1, 2, 100
+MD_NVE, MD_NVT = 0, 1
+
+# every symbol include/mdhip.h declares
+EXPORTS = [
+    "md_create", "md_destroy", "md_last_error", "md_set_potential", "md_set_potential_source", "md_set_skin",
+    "md_upload", "md_download", "md_compute_forces", "md_neighbor_pairs", "md_run", "md_kinetic",
+    "md_scale_velocities", "md_profile", "md_get_stats", "md_version",
+]
+
+
+class MdStats(C.Structure):
+    _fields_ = [("steps", C.c_int64), ("rebuilds", C.c_int64), ("violations", C.c_int64), ("n_ghost", C.c_int64),
+                ("max_neighbors", C.c_int64), ("avg_neighbors", C.c_double), ("force_launches", C.c_int64),
+                ("force_ms", C.c_double)]
+
+
+class MdhipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load libmdhip.so (fails loudly when it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise MdhipError(
+            f"{SO_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`make -C moleculardynamics/jl_amd/csrc`. There is no CPU fallback.")
+    L = C.CDLL(SO_PATH)
+    vp, dp, ip = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    L.md_create.argtypes = [C.c_int, C.c_int64, dp, C.c_double, C.c_int, C.POINTER(vp)]
+    L.md_create.restype = C.c_int
+    L.md_destroy.argtypes = [vp]
+    L.md_destroy.restype = C.c_int
+    L.md_last_error.argtypes = [vp]
+    L.md_last_error.restype = C.c_char_p
+    L.md_set_potential.argtypes = [vp, C.c_int, dp, C.c_int]
+    L.md_set_potential.restype = C.c_int
+    L.md_set_potential_source.argtypes = [vp, C.c_char_p, C.c_char_p, dp, C.c_int]
+    L.md_set_potential_source.restype = C.c_int
+    L.md_set_skin.argtypes = [vp, C.c_double]
+    L.md_set_skin.restype = C.c_int
+    L.md_upload.argtypes = [vp, dp, dp, dp, ip, dp]
+    L.md_upload.restype = C.c_int
+    L.md_download.argtypes = [vp, dp, dp, dp, ip]
+    L.md_download.restype = C.c_int
+    L.md_compute_forces.argtypes = [vp, dp, dp]
+    L.md_compute_forces.restype = C.c_int
+    L.md_neighbor_pairs.argtypes = [vp, ip, C.c_int64, C.POINTER(C.c_int64)]
+    L.md_neighbor_pairs.restype = C.c_int
+    L.md_run.argtypes = [vp, C.c_int64, C.c_double, C.c_int, C.c_double, C.c_double, dp, dp, dp, dp]
+    L.md_run.restype = C.c_int
+    L.md_kinetic.argtypes = [vp, dp]
+    L.md_kinetic.restype = C.c_int
+    L.md_scale_velocities.argtypes = [vp, C.c_double]
+    L.md_scale_velocities.restype = C.c_int
+    L.md_profile.argtypes = [vp, C.c_int]
+    L.md_profile.restype = C.c_int
+    L.md_get_stats.argtypes = [vp, C.POINTER(MdStats)]
+    L.md_get_stats.restype = C.c_int
+    L.md_version.argtypes = []
+    L.md_version.restype = C.c_char_p
+    _lib = L
+    return L

@@ -1,0 +1,716 @@
+// md_kernels.hpp -- gfx950 device code of libmdhip: linked-cell build with periodic ghost
+// copies, Verlet neighbour rows, the pair-force kernel (with the second velocity half-kick
+// and kinetic-energy partials fused into its epilogue), the first half-kick + drift kernel
+// and the small reductions.  fp64 throughout; no MFMA (the pair loop is not a contraction).
+//
+// Reference behaviour restated here (file:line into edwinb-ai/MolecularDynamics.jl):
+//   pair update            src/pairwise.jl:26-39
+//   LJ / PseudoHS          src/potentials.jl:66-77,160-164 / :1-29
+//   Polydisperse example   README.md:89-145
+//   half steps             src/integrate.jl:8-21,28-38 ; wrap src/boundary.jl:7-17
+//   KE / Bussi scale       src/thermostat.jl:20-67
+// Pair enumeration restates CellListMap.jl (un-vendored): translated ghost copies of the
+// particles near a periodic face, every pair accepted iff d^2 <= cutoff^2.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MD_BLOCK 256
+#define MD_WAVE 64
+#define MD_SENTINEL_POS 1.0e100
+#define MD_VAL_SRC_BITS 26
+#define MD_VAL_SRC_MASK ((1u << MD_VAL_SRC_BITS) - 1u)
+#define MD_NO_VIOLATION 0x7fffffff
+
+enum { POT_LJ = 0, POT_PSEUDOHS = 1, POT_POLYDISPERSE = 2, POT_CUSTOM = 100 };
+
+struct DevState {
+    double *x[3];  // cap+1 entries: owned [0,n), ghosts [n,next), sentinel at cap
+    double *v[3];  // n
+    double *f[3];  // n
+    double *sigma; // cap+1
+    int32_t *img[3];
+    int32_t *id;   // cap+1: original particle index (ghost: its owner's)
+    double *x0[3]; // n: positions at the last list build
+};
+
+struct BoxGrid {
+    double L[3], invL[3];
+    double inv_cell[3];
+    int nc[3];  // interior cells per dim
+    int ncx[3]; // extended (ghost-padded) cells per dim; 1 for an unused dim
+    int id_bits, cell_bits;
+};
+
+struct PotParams {
+    double p[8];
+    double c2;      // pair accepted iff d2 < c2 (strict form of d2 <= list_cutoff^2 folded with the potential's own r_cut where it has one)
+    double sig2u;   // uniform-diameter fast path: ((s+s)/2)^2
+    double sig_u;   // the uniform diameter itself
+};
+
+struct Scalars {
+    double U, W, K, scale, T;
+    unsigned long long max_disp2_bits;
+    int first_viol;
+    int overflow;
+    unsigned long long pair_count;
+};
+
+// ------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double md_rcp(double a)
+{
+    // v_rcp_f64 seed + two Newton steps: full fp64 accuracy for normal-range inputs at a
+    // fraction of the IEEE division sequence.
+    double r = __builtin_amdgcn_rcp(a);
+    double e = __builtin_fma(-a, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-a, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    return r;
+}
+
+__device__ __forceinline__ double md_ipow(double x, int n)
+{
+    double r = 1.0;
+    while (n) {
+        if (n & 1) r *= x;
+        x *= x;
+        n >>= 1;
+    }
+    return r;
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+__device__ __forceinline__ int wave_max_i(int v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off));
+    return v;
+}
+__device__ __forceinline__ double wave_max_d(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+    return v;
+}
+
+// deterministic block sum: wave shuffles, then wave 0 adds the per-wave results in order
+__device__ __forceinline__ double block_sum(double v, double *lds /* >= 16 doubles */)
+{
+    v = wave_sum(v);
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) lds[w] = v;
+    __syncthreads();
+    double r = 0.0;
+    for (int i = 0; i < nw; ++i) r += lds[i];
+    return r;
+}
+
+// XCD-aware bijective remap: hardware deals consecutive block ids round-robin over the 8
+// XCDs; give each XCD one contiguous range of logical tiles so a tile's neighbours (whose
+// positions it gathers) sit in the same XCD's L2.  Speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int bid, int nb)
+{
+    int q = nb >> 3, r = nb & 7;
+    int xcd = bid & 7, k = bid >> 3;
+    int start = xcd * q + (xcd < r ? xcd : r);
+    return start + k;
+}
+
+template <int D>
+__device__ __forceinline__ int cell_coord(double xc, int c, const BoxGrid &g)
+{
+    int cc = (int)(xc * g.inv_cell[c]);
+    cc = cc < 0 ? 0 : cc;
+    cc = cc > g.nc[c] - 1 ? g.nc[c] - 1 : cc;
+    return cc;
+}
+
+__device__ __forceinline__ int ext_linear(const int *e, const BoxGrid &g)
+{
+    return (e[2] * g.ncx[1] + e[1]) * g.ncx[0] + e[0];
+}
+
+// ------------------------------------------------------------------------------------------
+// pair potentials.  pair_eval returns u and fpr = f/r (so F_i += fpr * (x_i - x_j)),
+// f = -dU/dr being the reference's evaluate() contract.
+// ------------------------------------------------------------------------------------------
+#ifdef MD_HAVE_USER_POTENTIAL
+// supplied by the run-time compiled translation unit (md_set_potential_source)
+__device__ void MD_USER_ENTRY(double r, double s1, double s2, const double *params, double *u, double *f);
+#endif
+
+template <int POT, bool UNIFORM, bool WANT_U>
+__device__ __forceinline__ void pair_eval(double d2, double si, double sj, const PotParams &pp, double &u, double &fpr)
+{
+    if constexpr (POT == POT_LJ) {
+        // src/potentials.jl:66-77 in r^-2 form (no sqrt, one reciprocal)
+        double inv = md_rcp(d2);
+        double s2;
+        if constexpr (UNIFORM) {
+            s2 = pp.sig2u * inv;
+        } else {
+            double sg = (si + sj) * 0.5;
+            s2 = (sg * sg) * inv;
+        }
+        double s6 = s2 * s2 * s2;
+        double e24 = 24.0 * pp.p[0];
+        fpr = (e24 * inv) * (s6 * __builtin_fma(2.0, s6, -1.0));
+        if constexpr (WANT_U) u = (4.0 * pp.p[0]) * (s6 * (s6 - 1.0));
+    } else if constexpr (POT == POT_PSEUDOHS) {
+        // src/potentials.jl:11-29
+        double r = sqrt(d2);
+        double sg = UNIFORM ? pp.sig_u : (si + sj) / 2.0;
+        double lambda = pp.p[0];
+        double uij = 0.0, fij = 0.0;
+        if (r < 1.0204081632653061) {
+            double sr = sg / r;
+            double pl = pow(sr, lambda);
+            double plm = pow(sr, lambda - 1.0);
+            uij = 134.5526623421209 * (pl - plm) + 1.0;
+            fij = lambda * (pl * sr) - (lambda - 1.0) * pl;
+            fij *= 134.5526623421209;
+        }
+        u = uij;
+        fpr = fij / r;
+    } else if constexpr (POT == POT_POLYDISPERSE) {
+        // README.md:89-145
+        double r = sqrt(d2);
+        double se = 0.5 * (si + sj);
+        se *= (1.0 - pp.p[1] * fabs(si - sj));
+        double rc = pp.p[0];
+        double uij = 0.0, fij = 0.0;
+        if (r < rc * se) {
+            double c0 = -28.0 / md_ipow(rc, 12);
+            double c2 = 48.0 / md_ipow(rc, 14);
+            double c4 = -21.0 / md_ipow(rc, 16);
+            double q = r / se;
+            uij = md_ipow(se / r, 12) + c0 + c2 * (q * q) + c4 * md_ipow(q, 4);
+            fij = 12.0 * md_ipow(se, 12) / md_ipow(r, 13) - 2.0 * c2 * r / (se * se) -
+                  4.0 * c4 * (r * r * r) / md_ipow(se, 4);
+        }
+        u = uij;
+        fpr = fij / r;
+    } else {
+#ifdef MD_HAVE_USER_POTENTIAL
+        double r = sqrt(d2);
+        double uij, fij;
+        MD_USER_ENTRY(r, si, sj, pp.p, &uij, &fij);
+        u = uij;
+        fpr = fij / r;
+#else
+        u = 0.0;
+        fpr = 0.0;
+#endif
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// list build, stage 1: wrap the owned particles that left [0,L) (src/boundary.jl:7-17
+// arithmetic, applied lazily: only when a particle is actually outside the cell) and count
+// the periodic ghost copies each particle needs.
+// ------------------------------------------------------------------------------------------
+template <int D>
+__global__ void __launch_bounds__(MD_BLOCK) k_wrap_count(int n, DevState s, BoxGrid g, int32_t *__restrict__ nimg)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int cnt = 1;
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        double xc = s.x[c][i];
+        if (xc < 0.0 || xc >= g.L[c]) {
+            double frac = g.invL[c] * xc;
+            double nn = floor(frac);
+            double fm = frac - nn;
+            s.img[c][i] += (int32_t)nn;
+            xc = g.L[c] * fm;
+            s.x[c][i] = xc;
+        }
+        int cc = cell_coord<D>(xc, c, g);
+        if (cc == 0 || cc == g.nc[c] - 1) cnt *= 2;
+    }
+    nimg[i] = cnt - 1;
+}
+
+// stage 2: emit one sort entry per owned particle and per ghost copy.
+// key = [ghost bit | extended cell | original id]   val = [shift code (6 bits) | source slot]
+template <int D>
+__global__ void __launch_bounds__(MD_BLOCK)
+    k_emit(int n, DevState s, BoxGrid g, const int32_t *__restrict__ img_off, uint64_t *__restrict__ keys,
+           uint32_t *__restrict__ vals)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int cc[3] = {0, 0, 0}, b[3] = {0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        cc[c] = cell_coord<D>(s.x[c][i], c, g);
+        b[c] = (cc[c] == 0) ? 1 : ((cc[c] == g.nc[c] - 1) ? 2 : 0);
+    }
+    uint64_t idv = (uint64_t)(uint32_t)s.id[i];
+    int e[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) e[c] = (c < D) ? cc[c] + 1 : 0;
+    keys[i] = ((uint64_t)ext_linear(e, g) << g.id_bits) | idv;
+    vals[i] = (uint32_t)i;
+    int slot = n + img_off[i];
+    uint64_t gbit = 1ull << (g.id_bits + g.cell_bits);
+    for (int m = 1; m < (1 << D); ++m) {
+        bool ok = true;
+        uint32_t code = 0;
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            int mc = (m >> c) & 1;
+            if (mc) {
+                if (b[c] == 0) ok = false;
+                e[c] = (b[c] == 1) ? g.nc[c] + 1 : 0;
+                code |= (uint32_t)b[c] << (2 * c);
+            } else {
+                e[c] = cc[c] + 1;
+            }
+        }
+        if (!ok) continue;
+        keys[slot] = gbit | ((uint64_t)ext_linear(e, g) << g.id_bits) | idv;
+        vals[slot] = (uint32_t)i | (code << MD_VAL_SRC_BITS);
+        ++slot;
+    }
+}
+
+// stage 3 (after the radix sort): move every array into the new order, create the ghost
+// copies' translated coordinates, find the cell ranges.
+template <int D>
+__global__ void __launch_bounds__(MD_BLOCK)
+    k_gather(int n, int next, DevState so, DevState sn, BoxGrid g, const uint64_t *__restrict__ keys,
+             const uint32_t *__restrict__ vals, int32_t *__restrict__ newslot, int32_t *__restrict__ gsrc,
+             uint32_t *__restrict__ gcode, int32_t *__restrict__ cell_start, int32_t *__restrict__ cell_end)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= next) return;
+    uint64_t key = keys[k];
+    uint32_t val = vals[k];
+    int src = (int)(val & MD_VAL_SRC_MASK);
+    uint32_t code = val >> MD_VAL_SRC_BITS;
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        double xc = so.x[c][src];
+        uint32_t sh = (code >> (2 * c)) & 3u;
+        if (sh == 1u) xc = xc + g.L[c];
+        if (sh == 2u) xc = xc - g.L[c];
+        sn.x[c][k] = xc;
+    }
+    sn.sigma[k] = so.sigma[src];
+    sn.id[k] = so.id[src];
+    if (k < n) {
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            sn.v[c][k] = so.v[c][src];
+            sn.f[c][k] = so.f[c][src];
+            sn.img[c][k] = so.img[c][src];
+            sn.x0[c][k] = sn.x[c][k];
+        }
+        newslot[src] = k;
+    } else {
+        gsrc[k - n] = src;
+        gcode[k - n] = code;
+    }
+    uint64_t cmask = (1ull << (g.cell_bits + 1)) - 1ull; // ghost bit kept: owned and ghost runs never merge
+    int ce = (int)((key >> g.id_bits) & cmask);
+    int cprev = (k > 0) ? (int)((keys[k - 1] >> g.id_bits) & cmask) : -1;
+    int cellmask = (1 << g.cell_bits) - 1;
+    if (ce != cprev) {
+        cell_start[ce & cellmask] = k;
+        if (k > 0) cell_end[cprev & cellmask] = k;
+    }
+    if (k == next - 1) cell_end[ce & cellmask] = next;
+}
+
+__global__ void __launch_bounds__(MD_BLOCK)
+    k_ghost_owner(int nghost, const int32_t *__restrict__ gsrc, const int32_t *__restrict__ newslot,
+                  int32_t *__restrict__ gowner)
+{
+    int gi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi >= nghost) return;
+    gowner[gi] = newslot[gsrc[gi]];
+}
+
+// ghost copies follow their owners between builds: x_ghost = x_owner + s*L
+template <int D>
+__global__ void __launch_bounds__(MD_BLOCK)
+    k_ghost_update(int n, int nghost, DevState s, BoxGrid g, const int32_t *__restrict__ gowner,
+                   const uint32_t *__restrict__ gcode, const Scalars *__restrict__ sc, int step)
+{
+    int gi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gi >= nghost) return;
+    if (sc->first_viol <= step) return;
+    int o = gowner[gi];
+    uint32_t code = gcode[gi];
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        double xc = s.x[c][o];
+        uint32_t sh = (code >> (2 * c)) & 3u;
+        if (sh == 1u) xc = xc + g.L[c];
+        if (sh == 2u) xc = xc - g.L[c];
+        s.x[c][n + gi] = xc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Verlet rows.  One lane per owned particle, 27 (9 in 2-D) extended cells swept; row k lives
+// transposed in 64-particle tiles: nlist[(tile*maxn + r)*64 + lane], so a wave's r-th
+// neighbour indices are one coalesced 256-byte read.  Rows are padded to the wave maximum
+// (rounded up to a multiple of 4) with the sentinel slot, which sits 1e100 away.
+// ------------------------------------------------------------------------------------------
+template <int D>
+__global__ void __launch_bounds__(MD_BLOCK)
+    k_build_list(int n, DevState s, BoxGrid g, double rl2, const int32_t *__restrict__ cell_start,
+                 const int32_t *__restrict__ cell_end, uint32_t *__restrict__ nlist, int maxn,
+                 int32_t *__restrict__ nneigh, int32_t *__restrict__ nmax_tile, uint32_t sentinel, Scalars *sc)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    bool active = k < n;
+    int lane = threadIdx.x & 63;
+    int tile = k >> 6;
+    uint32_t *row = nlist + ((size_t)tile * maxn) * 64 + lane;
+    int cnt = 0;
+    if (active) {
+        double xi[3] = {0, 0, 0};
+        int ec[3] = {0, 0, 0};
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            xi[c] = s.x[c][k];
+            ec[c] = cell_coord<D>(xi[c], c, g) + 1;
+        }
+        int z0 = (D == 3) ? -1 : 0, z1 = (D == 3) ? 1 : 0;
+        for (int dz = z0; dz <= z1; ++dz)
+            for (int dy = -1; dy <= 1; ++dy)
+                for (int dx = -1; dx <= 1; ++dx) {
+                    int e[3] = {ec[0] + dx, ec[1] + dy, (D == 3) ? ec[2] + dz : 0};
+                    int cell = ext_linear(e, g);
+                    int js = cell_start[cell], je = cell_end[cell];
+                    for (int j = js; j < je; ++j) {
+                        double ddx = s.x[0][j] - xi[0];
+                        double ddy = s.x[1][j] - xi[1];
+                        double d2 = ddx * ddx;
+                        d2 = __builtin_fma(ddy, ddy, d2);
+                        if constexpr (D == 3) {
+                            double ddz = s.x[2][j] - xi[2];
+                            d2 = __builtin_fma(ddz, ddz, d2);
+                        }
+                        if (d2 <= rl2 && j != k) {
+                            if (cnt < maxn) row[(size_t)cnt * 64] = (uint32_t)j;
+                            ++cnt;
+                        }
+                    }
+                }
+        nneigh[k] = cnt;
+        if (cnt > maxn) {
+            atomicOr(&sc->overflow, 1);
+            cnt = maxn;
+        }
+    }
+    int m = wave_max_i(cnt);
+    m = (m + 3) & ~3;
+    if (m > maxn) m = maxn; // maxn is a multiple of 4
+    for (int t = cnt; t < m; ++t) row[(size_t)t * 64] = sentinel;
+    if (lane == 0) nmax_tile[tile] = m;
+}
+
+// ------------------------------------------------------------------------------------------
+// The force kernel.  One lane per owned particle; neighbour coordinates are gathered by
+// index (ghost copies carry translated coordinates, so there is no minimum-image arithmetic
+// in the loop).  Full-neighbour form: every pair is evaluated from both ends, no scatter, no
+// atomics, bitwise reproducible.  Epilogue: F store, optional second half-kick
+// v += (F*dt)/2 (src/integrate.jl:33) and per-block partials of sum v^2, U, W.
+// ------------------------------------------------------------------------------------------
+template <int D, int POT, bool UNIFORM, bool WANT_UW, bool KICK>
+__global__ void __launch_bounds__(MD_BLOCK)
+    k_force(int n, DevState s, PotParams pp, const uint32_t *__restrict__ nlist, int maxn,
+            const int32_t *__restrict__ nmax_tile, double dt, double *__restrict__ partials, int nblk_total,
+            const Scalars *__restrict__ sc, int step)
+{
+    __shared__ double red[16];
+    if (sc->first_viol <= step) return;
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    int k = bid * MD_BLOCK + threadIdx.x;
+    bool active = k < n;
+    int kk = active ? k : n - 1;
+    int lane = threadIdx.x & 63;
+    int tile = kk >> 6;
+    const uint32_t *row = nlist + ((size_t)tile * maxn) * 64 + lane;
+    int m = nmax_tile[tile];
+    double xi = s.x[0][kk], yi = s.x[1][kk], zi = 0.0;
+    if constexpr (D == 3) zi = s.x[2][kk];
+    double si = 0.0;
+    if constexpr (!UNIFORM) si = s.sigma[kk];
+    double fx = 0.0, fy = 0.0, fz = 0.0, us = 0.0, ws = 0.0;
+    const double *__restrict__ X = s.x[0];
+    const double *__restrict__ Y = s.x[1];
+    const double *__restrict__ Z = s.x[2];
+    const double *__restrict__ S = s.sigma;
+    for (int r = 0; r < m; r += 4) {
+        uint32_t j[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) j[q] = row[(size_t)(r + q) * 64];
+        double xj[4], yj[4], zj[4], sj[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            xj[q] = X[j[q]];
+            yj[q] = Y[j[q]];
+            if constexpr (D == 3) zj[q] = Z[j[q]];
+            if constexpr (!UNIFORM) sj[q] = S[j[q]];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            double dx = xj[q] - xi;
+            double dy = yj[q] - yi;
+            double d2 = dx * dx;
+            d2 = __builtin_fma(dy, dy, d2);
+            double dz = 0.0;
+            if constexpr (D == 3) {
+                dz = zj[q] - zi;
+                d2 = __builtin_fma(dz, dz, d2);
+            }
+            bool hit = d2 < pp.c2;
+            double u = 0.0, fpr;
+            pair_eval<POT, UNIFORM, WANT_UW>(d2, si, UNIFORM ? 0.0 : sj[q], pp, u, fpr);
+            fpr = hit ? fpr : 0.0;
+            // F_i += f * (x_i - x_j)/r = -fpr * d
+            fx = __builtin_fma(-fpr, dx, fx);
+            fy = __builtin_fma(-fpr, dy, fy);
+            if constexpr (D == 3) fz = __builtin_fma(-fpr, dz, fz);
+            if constexpr (WANT_UW) {
+                us += hit ? u : 0.0;
+                ws = __builtin_fma(fpr, d2, ws);
+            }
+        }
+    }
+    double ke = 0.0;
+    if (active) {
+        s.f[0][k] = fx;
+        s.f[1][k] = fy;
+        if constexpr (D == 3) s.f[2][k] = fz;
+        if constexpr (KICK) {
+            double vx = s.v[0][k] + (fx * dt) / 2.0;
+            double vy = s.v[1][k] + (fy * dt) / 2.0;
+            s.v[0][k] = vx;
+            s.v[1][k] = vy;
+            ke = vx * vx + vy * vy;
+            if constexpr (D == 3) {
+                double vz = s.v[2][k] + (fz * dt) / 2.0;
+                s.v[2][k] = vz;
+                ke += vz * vz;
+            }
+        }
+    } else {
+        us = 0.0;
+        ws = 0.0;
+    }
+    if constexpr (KICK) {
+        double t = block_sum(ke, red);
+        if (threadIdx.x == 0) partials[bid] = t;
+    }
+    if constexpr (WANT_UW) {
+        double tu = block_sum(us, red);
+        double tw = block_sum(ws, red);
+        if (threadIdx.x == 0) {
+            partials[nblk_total + bid] = tu;
+            partials[2 * nblk_total + bid] = tw;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// First half of velocity Verlet (src/integrate.jl:14-15):  v += (f*dt)/2 ; x += v*dt, with
+// the pending Bussi rescale of the previous step folded in front (v *= scale,
+// src/thermostat.jl:43-45).  Wrapping is deferred to the next list build; the displacement
+// since the last build is checked against (skin/2)^2 and the first violating step recorded.
+// ------------------------------------------------------------------------------------------
+template <int D, bool SCALE>
+__global__ void __launch_bounds__(MD_BLOCK) k_kickdrift(int n, DevState s, double dt, double thr2, Scalars *sc, int step)
+{
+    if (sc->first_viol < step) return;
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    double disp2 = 0.0;
+    if (k < n) {
+        double scale = 1.0;
+        if constexpr (SCALE) scale = sc->scale;
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            double vc = s.v[c][k];
+            if constexpr (SCALE) vc = vc * scale;
+            vc = vc + (s.f[c][k] * dt) / 2.0;
+            s.v[c][k] = vc;
+            double xc = s.x[c][k] + vc * dt;
+            s.x[c][k] = xc;
+            double d = xc - s.x0[c][k];
+            disp2 = __builtin_fma(d, d, disp2);
+        }
+    }
+    double wm = wave_max_d(disp2);
+    if ((threadIdx.x & 63) == 0) {
+        if (wm > thr2) atomicMin(&sc->first_viol, step);
+        atomicMax(&sc->max_disp2_bits, (unsigned long long)__double_as_longlong(wm));
+    }
+}
+
+template <int D>
+__global__ void __launch_bounds__(MD_BLOCK) k_scale_v(int n, DevState s, const Scalars *sc, double host_scale, int use_dev)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    double scale = use_dev ? sc->scale : host_scale;
+#pragma unroll
+    for (int c = 0; c < D; ++c) s.v[c][k] = s.v[c][k] * scale;
+}
+
+template <int D>
+__global__ void __launch_bounds__(MD_BLOCK) k_ke_partials(int n, DevState s, double *__restrict__ partials)
+{
+    __shared__ double red[16];
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    double ke = 0.0;
+    if (k < n) {
+#pragma unroll
+        for (int c = 0; c < D; ++c) ke += s.v[c][k] * s.v[c][k];
+    }
+    double t = block_sum(ke, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+// One block: fixed-order sums of the per-block partials -> K (and U, W), then the Bussi
+// scale of this step (src/thermostat.jl:20-41) from the host-drawn r1, r2.
+__global__ void __launch_bounds__(1024)
+    k_finalize(int nblk, const double *__restrict__ partials, int want_uw, int nvt, double nf, double term1,
+               const double *__restrict__ kt, const double *__restrict__ r1, const double *__restrict__ r2,
+               Scalars *sc, int step)
+{
+    __shared__ double red[16];
+    if (sc->first_viol <= step) return;
+    double a = 0.0, b = 0.0, c = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += blockDim.x) {
+        a += partials[i];
+        if (want_uw) {
+            b += partials[nblk + i];
+            c += partials[2 * nblk + i];
+        }
+    }
+    a = block_sum(a, red);
+    if (want_uw) {
+        b = block_sum(b, red);
+        c = block_sum(c, red);
+    }
+    if (threadIdx.x == 0) {
+        double K = a / 2.0;
+        if (want_uw) {
+            sc->U = b / 2.0; // every pair was evaluated from both ends
+            sc->W = c / 2.0;
+        }
+        if (nvt) {
+            double tc = 2.0 * K / nf;
+            double rr1 = r1[step], rr2 = r2[step];
+            double c2 = (1.0 - term1) * kt[step] / (tc * nf);
+            double term_2 = c2 * (rr2 + rr1 * rr1);
+            double term_3 = 2.0 * rr1 * sqrt(term1 * c2);
+            double scale = sqrt(term1 + term_2 + term_3);
+            sc->scale = scale;
+            K = K * scale * scale;
+        }
+        sc->K = K;
+        sc->T = 2.0 * K / nf;
+    }
+}
+
+__global__ void k_set_scale(Scalars *sc, double v) { sc->scale = v; }
+
+// ------------------------------------------------------------------------------------------
+// Accepted pair set for the parity check: (min id, max id) for every list entry with
+// d^2 <= cutoff^2, emitted from the lower-id end only (orientation a -> b, a < b).
+// ------------------------------------------------------------------------------------------
+template <int D>
+__global__ void __launch_bounds__(MD_BLOCK)
+    k_pairs(int n, DevState s, double c2_inclusive, const uint32_t *__restrict__ nlist, int maxn,
+            const int32_t *__restrict__ nneigh, int32_t *__restrict__ out, unsigned long long cap, Scalars *sc)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    int lane = threadIdx.x & 63, tile = k >> 6;
+    const uint32_t *row = nlist + ((size_t)tile * maxn) * 64 + lane;
+    int cnt = nneigh[k];
+    int a = s.id[k];
+    for (int r = 0; r < cnt; ++r) {
+        uint32_t j = row[(size_t)r * 64];
+        int b = s.id[j];
+        if (a >= b) continue;
+        double dx = s.x[0][j] - s.x[0][k];
+        double dy = s.x[1][j] - s.x[1][k];
+        double d2 = dx * dx;
+        d2 = __builtin_fma(dy, dy, d2);
+        if constexpr (D == 3) {
+            double dz = s.x[2][j] - s.x[2][k];
+            d2 = __builtin_fma(dz, dz, d2);
+        }
+        if (d2 <= c2_inclusive) {
+            unsigned long long p = atomicAdd(&sc->pair_count, 1ull);
+            if (p < cap) {
+                out[2 * p] = a;
+                out[2 * p + 1] = b;
+            }
+        }
+    }
+}
+
+// download helper: wrapped copy of the positions + images without touching the state
+template <int D>
+__global__ void __launch_bounds__(MD_BLOCK)
+    k_export(int n, DevState s, BoxGrid g, double *__restrict__ xo, double *__restrict__ vo, double *__restrict__ fo,
+             int32_t *__restrict__ io)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    size_t o = (size_t)s.id[k] * D;
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        double xc = s.x[c][k];
+        int32_t im = s.img[c][k];
+        if (xc < 0.0 || xc >= g.L[c]) {
+            double frac = g.invL[c] * xc;
+            double nn = floor(frac);
+            im += (int32_t)nn;
+            xc = g.L[c] * (frac - nn);
+        }
+        xo[o + c] = xc;
+        io[o + c] = im;
+        vo[o + c] = s.v[c][k];
+        fo[o + c] = s.f[c][k];
+    }
+}
+
+template <int D>
+__global__ void __launch_bounds__(MD_BLOCK)
+    k_import(int n, DevState s, const double *__restrict__ xi, const double *__restrict__ vi,
+             const double *__restrict__ fi, const int32_t *__restrict__ ii, const double *__restrict__ di)
+{
+    // host order -> current device order (slot k holds original particle id[k])
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    size_t o = (size_t)s.id[k] * D;
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        if (xi) s.x[c][k] = xi[o + c];
+        if (vi) s.v[c][k] = vi[o + c];
+        if (fi) s.f[c][k] = fi[o + c];
+        if (ii) s.img[c][k] = ii[o + c];
+    }
+    if (di) s.sigma[k] = di[s.id[k]];
+}

@@ -1,0 +1,971 @@
+// mdhip.hip -- host side of libmdhip.so: device-resident state, list (re)builds, the step
+// loop and the extern "C" boundary declared in include/mdhip.h.
+//
+// Reference call stack this replaces: run_simulation! (src/simulation.jl:88-108) ->
+// integrate_half! / reset_output! / CellListMap.map_pairwise! / integrate_second_half! /
+// ensemble_step!.  See md_kernels.hpp for the kernels and DESIGN.md for the data layout.
+#include <cstring>
+#include <cstdlib>
+
+#include "md_kernels.hpp"
+
+#include <rocprim/rocprim.hpp>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../../include/mdhip.h"
+
+namespace {
+
+struct HipError : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+#define HIPCHK(expr)                                                                                        \
+    do {                                                                                                    \
+        hipError_t e_ = (expr);                                                                             \
+        if (e_ != hipSuccess) {                                                                             \
+            char buf_[512];                                                                                 \
+            snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__,    \
+                     __LINE__);                                                                             \
+            throw HipError(buf_);                                                                           \
+        }                                                                                                   \
+    } while (0)
+
+template <class T>
+struct DBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    void alloc(size_t count)
+    {
+        release();
+        if (count == 0) count = 1;
+        HIPCHK(hipMalloc((void **)&p, count * sizeof(T)));
+        n = count;
+    }
+    void ensure(size_t count)
+    {
+        if (count > n) alloc(count + count / 4 + 16);
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    ~DBuf() { release(); }
+};
+
+struct StateBufs {
+    DBuf<double> x[3], v[3], f[3], sigma, x0[3];
+    DBuf<int32_t> img[3], id;
+};
+
+inline int ceil_log2(uint64_t v)
+{
+    int b = 0;
+    while ((1ull << b) < v) ++b;
+    return b;
+}
+
+std::string g_create_error;
+
+} // namespace
+
+struct md_ctx {
+    int dim = 3;
+    int64_t n = 0;
+    double L[3] = {1, 1, 1};
+    double rc = 0.0;       // list cutoff (CellListMap's cutoff)
+    double skin_req = 0.3; // requested skin
+    double skin = 0.0;     // effective skin
+    double rl = 0.0;       // rc + skin
+    int pot_kind = POT_LJ;
+    PotParams pp{};
+    bool uniform_sigma = true;
+    double sigma_u = 1.0;
+    int device = 0;
+    hipStream_t stream = nullptr;
+
+    int64_t cap = 0;  // extended capacity: owned + ghosts (sentinel lives at index cap)
+    int64_t next = 0; // owned + ghosts of the last build
+    int64_t nghost = 0;
+    StateBufs sb[2];
+    int cur = 0;
+    BoxGrid grid{};
+    int ncell_ext = 0;
+
+    DBuf<int32_t> nimg, img_off, newslot, gsrc, gowner, cell_start, cell_end, nneigh, nmax_tile;
+    DBuf<uint32_t> gcode, vals_in, vals_out, nlist;
+    DBuf<uint64_t> keys_in, keys_out;
+    DBuf<char> sort_tmp, scan_tmp;
+    int maxn = 0;
+    int64_t ntiles = 0;
+
+    DBuf<double> partials;
+    int nblk = 0;
+    DBuf<Scalars> scal;
+    DBuf<double> d_kt, d_r1, d_r2;
+
+    DBuf<double> io_x, io_v, io_f, io_d;
+    DBuf<int32_t> io_i;
+
+    bool list_valid = false;
+    int64_t steps_since_build = 0;
+    int64_t target_interval = 8;
+
+    // stats / profiling
+    int64_t st_steps = 0, st_rebuilds = 0, st_viol = 0;
+    bool prof = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
+    size_t prof_used = 0;
+    double prof_ms_acc = 0.0;
+    int64_t prof_launch_acc = 0;
+
+    std::string err;
+
+    DevState dev(int which)
+    {
+        DevState s{};
+        StateBufs &b = sb[which];
+        for (int c = 0; c < 3; ++c) {
+            s.x[c] = b.x[c].p;
+            s.v[c] = b.v[c].p;
+            s.f[c] = b.f[c].p;
+            s.img[c] = b.img[c].p;
+            s.x0[c] = b.x0[c].p;
+        }
+        s.sigma = b.sigma.p;
+        s.id = b.id.p;
+        return s;
+    }
+};
+
+namespace {
+
+inline int nblocks(int64_t n) { return (int)((n + MD_BLOCK - 1) / MD_BLOCK); }
+
+__global__ void k_init_state(int n, int64_t cap, DevState s, int dim)
+{
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k > cap) return;
+    bool sent = (k == cap);
+    for (int c = 0; c < dim; ++c) s.x[c][k] = sent ? MD_SENTINEL_POS : 0.0;
+    s.sigma[k] = 1.0;
+    s.id[k] = sent ? -1 : (k < n ? (int32_t)k : 0);
+    if (k < n)
+        for (int c = 0; c < dim; ++c) {
+            s.v[c][k] = 0.0;
+            s.f[c][k] = 0.0;
+            s.img[c][k] = 0;
+            s.x0[c][k] = 0.0;
+        }
+}
+
+__global__ void k_reset_flags(Scalars *sc)
+{
+    sc->first_viol = MD_NO_VIOLATION;
+    sc->max_disp2_bits = 0ull;
+    sc->overflow = 0;
+}
+
+void alloc_state(md_ctx *c, int which, int64_t cap)
+{
+    StateBufs &b = c->sb[which];
+    for (int d = 0; d < c->dim; ++d) {
+        b.x[d].alloc(cap + 1);
+        b.v[d].alloc(c->n);
+        b.f[d].alloc(c->n);
+        b.img[d].alloc(c->n);
+        b.x0[d].alloc(c->n);
+    }
+    b.sigma.alloc(cap + 1);
+    b.id.alloc(cap + 1);
+}
+
+// (re)derive the cell grid from box, cutoff and skin
+void configure_grid(md_ctx *c)
+{
+    double lmin = c->L[0];
+    for (int d = 1; d < c->dim; ++d) lmin = std::min(lmin, c->L[d]);
+    if (lmin / 3.0 < c->rc) {
+        char b[256];
+        snprintf(b, sizeof b,
+                 "box too small for the linked-cell build: need every box length >= 3*list_cutoff (L_min=%g, "
+                 "list_cutoff=%g)",
+                 lmin, c->rc);
+        throw HipError(b);
+    }
+    double skin = std::max(0.0, c->skin_req);
+    double smax = lmin / 3.0 - c->rc;
+    if (skin > smax) skin = std::max(0.0, smax * 0.999);
+    c->skin = skin;
+    c->rl = c->rc + skin;
+    BoxGrid &g = c->grid;
+    int64_t ncell = 1;
+    for (int d = 0; d < 3; ++d) {
+        if (d < c->dim) {
+            g.L[d] = c->L[d];
+            g.invL[d] = 1.0 / c->L[d];
+            int k = (int)std::floor(c->L[d] / c->rl);
+            // guard against floor() landing one too high through rounding
+            while (k > 3 && c->L[d] / k < c->rl) --k;
+            if (k < 3) k = 3;
+            g.nc[d] = k;
+            g.ncx[d] = k + 2;
+            g.inv_cell[d] = (double)k / c->L[d];
+        } else {
+            g.L[d] = 1.0;
+            g.invL[d] = 1.0;
+            g.nc[d] = 1;
+            g.ncx[d] = 1;
+            g.inv_cell[d] = 0.0;
+        }
+        ncell *= g.ncx[d];
+    }
+    if (ncell > (1ll << 30)) throw HipError("cell grid too large");
+    c->ncell_ext = (int)ncell;
+    g.id_bits = std::max(1, ceil_log2((uint64_t)c->n));
+    g.cell_bits = std::max(1, ceil_log2((uint64_t)ncell));
+    c->cell_start.ensure(ncell + 1);
+    c->cell_end.ensure(ncell + 1);
+    c->list_valid = false;
+}
+
+void configure_potential(md_ctx *c)
+{
+    double c2_incl = c->rc * c->rc;
+    double c2 = std::nextafter(c2_incl, INFINITY); // d2 < c2  <=>  d2 <= rc^2
+    if (c->pot_kind == POT_LJ) {
+        // r >= r_cut -> (0,0): src/potentials.jl:67-69
+        double rcp2 = c->pp.p[2] * c->pp.p[2];
+        c2 = std::min(c2, rcp2);
+    }
+    c->pp.c2 = c2;
+    c->pp.sig_u = c->sigma_u;
+    c->pp.sig2u = ((c->sigma_u + c->sigma_u) * 0.5) * ((c->sigma_u + c->sigma_u) * 0.5);
+}
+
+void ensure_capacity(md_ctx *c, int64_t need_next)
+{
+    if (need_next <= c->cap) return;
+    int64_t newcap = need_next + need_next / 8 + 1024;
+    // grow both state buffers, preserving the current one's owned entries
+    int dim = c->dim;
+    for (int w = 0; w < 2; ++w) {
+        StateBufs &b = c->sb[w];
+        for (int d = 0; d < dim; ++d) {
+            DBuf<double> nx;
+            nx.alloc(newcap + 1);
+            if (w == c->cur) HIPCHK(hipMemcpyAsync(nx.p, b.x[d].p, sizeof(double) * c->n, hipMemcpyDeviceToDevice, c->stream));
+            double sent = MD_SENTINEL_POS;
+            HIPCHK(hipMemcpyAsync(nx.p + newcap, &sent, sizeof(double), hipMemcpyHostToDevice, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            std::swap(b.x[d].p, nx.p);
+            std::swap(b.x[d].n, nx.n);
+        }
+        DBuf<double> ns;
+        ns.alloc(newcap + 1);
+        DBuf<int32_t> ni;
+        ni.alloc(newcap + 1);
+        if (w == c->cur) {
+            HIPCHK(hipMemcpyAsync(ns.p, b.sigma.p, sizeof(double) * c->n, hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(hipMemcpyAsync(ni.p, b.id.p, sizeof(int32_t) * c->n, hipMemcpyDeviceToDevice, c->stream));
+        }
+        double one = 1.0;
+        int32_t m1 = -1;
+        HIPCHK(hipMemcpyAsync(ns.p + newcap, &one, sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(ni.p + newcap, &m1, sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        std::swap(b.sigma.p, ns.p);
+        std::swap(b.sigma.n, ns.n);
+        std::swap(b.id.p, ni.p);
+        std::swap(b.id.n, ni.n);
+    }
+    c->cap = newcap;
+    c->keys_in.ensure(newcap);
+    c->keys_out.ensure(newcap);
+    c->vals_in.ensure(newcap);
+    c->vals_out.ensure(newcap);
+    c->gsrc.ensure(newcap - c->n + 1);
+    c->gcode.ensure(newcap - c->n + 1);
+    c->gowner.ensure(newcap - c->n + 1);
+}
+
+template <int D>
+void rebuild_t(md_ctx *c)
+{
+    hipStream_t st = c->stream;
+    int n = (int)c->n;
+    int nb = nblocks(n);
+    DevState so = c->dev(c->cur);
+    BoxGrid g = c->grid;
+
+    k_wrap_count<D><<<nb, MD_BLOCK, 0, st>>>(n, so, g, c->nimg.p);
+    // exclusive scan over n+1 items (nimg[n] == 0 by construction) -> img_off[n] = #ghosts
+    size_t tmp_bytes = 0;
+    HIPCHK(rocprim::exclusive_scan(nullptr, tmp_bytes, c->nimg.p, c->img_off.p, (int32_t)0, (size_t)n + 1,
+                                   rocprim::plus<int32_t>(), st));
+    c->scan_tmp.ensure(tmp_bytes);
+    HIPCHK(rocprim::exclusive_scan(c->scan_tmp.p, tmp_bytes, c->nimg.p, c->img_off.p, (int32_t)0, (size_t)n + 1,
+                                   rocprim::plus<int32_t>(), st));
+    int32_t nghost = 0;
+    HIPCHK(hipMemcpyAsync(&nghost, c->img_off.p + n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    int64_t next = (int64_t)n + nghost;
+    ensure_capacity(c, next);
+    so = c->dev(c->cur);
+    DevState sn = c->dev(c->cur ^ 1);
+
+    k_emit<D><<<nb, MD_BLOCK, 0, st>>>(n, so, g, c->img_off.p, c->keys_in.p, c->vals_in.p);
+    unsigned end_bit = (unsigned)(g.id_bits + g.cell_bits + 1);
+    tmp_bytes = 0;
+    HIPCHK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, c->keys_in.p, c->keys_out.p, c->vals_in.p, c->vals_out.p,
+                                     (size_t)next, 0u, end_bit, st));
+    c->sort_tmp.ensure(tmp_bytes);
+    HIPCHK(rocprim::radix_sort_pairs(c->sort_tmp.p, tmp_bytes, c->keys_in.p, c->keys_out.p, c->vals_in.p,
+                                     c->vals_out.p, (size_t)next, 0u, end_bit, st));
+    HIPCHK(hipMemsetAsync(c->cell_start.p, 0, sizeof(int32_t) * (c->ncell_ext + 1), st));
+    HIPCHK(hipMemsetAsync(c->cell_end.p, 0, sizeof(int32_t) * (c->ncell_ext + 1), st));
+    k_gather<D><<<nblocks(next), MD_BLOCK, 0, st>>>(n, (int)next, so, sn, g, c->keys_out.p, c->vals_out.p,
+                                                     c->newslot.p, c->gsrc.p, c->gcode.p, c->cell_start.p,
+                                                     c->cell_end.p);
+    if (nghost > 0)
+        k_ghost_owner<<<nblocks(nghost), MD_BLOCK, 0, st>>>(nghost, c->gsrc.p, c->newslot.p, c->gowner.p);
+    c->cur ^= 1;
+    c->next = next;
+    c->nghost = nghost;
+
+    // neighbour rows
+    double rl2 = c->rl * c->rl;
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        k_reset_flags<<<1, 1, 0, st>>>(c->scal.p);
+        k_build_list<D><<<nb, MD_BLOCK, 0, st>>>(n, sn, g, rl2, c->cell_start.p, c->cell_end.p, c->nlist.p, c->maxn,
+                                                 c->nneigh.p, c->nmax_tile.p, (uint32_t)c->cap, c->scal.p);
+        Scalars h;
+        HIPCHK(hipMemcpyAsync(&h, c->scal.p, sizeof(Scalars), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (!h.overflow) break;
+        if (attempt == 7) throw HipError("neighbour rows keep overflowing");
+        c->maxn = ((c->maxn * 3 / 2) + 3) & ~3;
+        c->nlist.alloc((size_t)c->ntiles * c->maxn * 64);
+    }
+    c->list_valid = true;
+    c->steps_since_build = 0;
+    c->st_rebuilds++;
+}
+
+void rebuild(md_ctx *c)
+{
+    if (c->dim == 3)
+        rebuild_t<3>(c);
+    else
+        rebuild_t<2>(c);
+    HIPCHK(hipGetLastError());
+}
+
+void prof_begin(md_ctx *c)
+{
+    if (!c->prof) return;
+    if (c->prof_used >= c->prof_ev.size()) {
+        if (c->prof_ev.size() >= 4096) return;
+        hipEvent_t a, b;
+        HIPCHK(hipEventCreate(&a));
+        HIPCHK(hipEventCreate(&b));
+        c->prof_ev.emplace_back(a, b);
+    }
+    HIPCHK(hipEventRecord(c->prof_ev[c->prof_used].first, c->stream));
+}
+void prof_end(md_ctx *c)
+{
+    if (!c->prof) return;
+    if (c->prof_used >= c->prof_ev.size()) return;
+    HIPCHK(hipEventRecord(c->prof_ev[c->prof_used].second, c->stream));
+    c->prof_used++;
+}
+void prof_collect(md_ctx *c)
+{
+    if (c->prof_used == 0) return;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < c->prof_used; ++i) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, c->prof_ev[i].first, c->prof_ev[i].second));
+        c->prof_ms_acc += ms;
+        c->prof_launch_acc++;
+    }
+    c->prof_used = 0;
+}
+
+template <int D, int POT, bool UNIFORM>
+void launch_force_tpu(md_ctx *c, bool want_uw, bool kick, double dt, int step)
+{
+    int n = (int)c->n;
+    DevState s = c->dev(c->cur);
+    int nb = c->nblk;
+#define LF(UW, KK)                                                                                                  \
+    k_force<D, POT, UNIFORM, UW, KK><<<nb, MD_BLOCK, 0, c->stream>>>(n, s, c->pp, c->nlist.p, c->maxn,              \
+                                                                     c->nmax_tile.p, dt, c->partials.p, nb,         \
+                                                                     c->scal.p, step)
+    prof_begin(c);
+    if (want_uw) {
+        if (kick)
+            LF(true, true);
+        else
+            LF(true, false);
+    } else {
+        if (kick)
+            LF(false, true);
+        else
+            LF(false, false);
+    }
+    prof_end(c);
+#undef LF
+}
+
+template <int D>
+void launch_force_d(md_ctx *c, bool want_uw, bool kick, double dt, int step)
+{
+    bool u = c->uniform_sigma;
+    switch (c->pot_kind) {
+    case POT_LJ:
+        if (u)
+            launch_force_tpu<D, POT_LJ, true>(c, want_uw, kick, dt, step);
+        else
+            launch_force_tpu<D, POT_LJ, false>(c, want_uw, kick, dt, step);
+        break;
+    case POT_PSEUDOHS:
+        if (u)
+            launch_force_tpu<D, POT_PSEUDOHS, true>(c, want_uw, kick, dt, step);
+        else
+            launch_force_tpu<D, POT_PSEUDOHS, false>(c, want_uw, kick, dt, step);
+        break;
+    case POT_POLYDISPERSE:
+        launch_force_tpu<D, POT_POLYDISPERSE, false>(c, want_uw, kick, dt, step);
+        break;
+    default:
+        throw HipError("potential kind not available (custom potentials need md_set_potential_source)");
+    }
+}
+
+void launch_force(md_ctx *c, bool want_uw, bool kick, double dt, int step)
+{
+    if (c->dim == 3)
+        launch_force_d<3>(c, want_uw, kick, dt, step);
+    else
+        launch_force_d<2>(c, want_uw, kick, dt, step);
+}
+
+void launch_kickdrift(md_ctx *c, bool nvt, double dt, double thr2, int step)
+{
+    int n = (int)c->n;
+    DevState s = c->dev(c->cur);
+    int nb = c->nblk;
+    if (c->dim == 3) {
+        if (nvt)
+            k_kickdrift<3, true><<<nb, MD_BLOCK, 0, c->stream>>>(n, s, dt, thr2, c->scal.p, step);
+        else
+            k_kickdrift<3, false><<<nb, MD_BLOCK, 0, c->stream>>>(n, s, dt, thr2, c->scal.p, step);
+    } else {
+        if (nvt)
+            k_kickdrift<2, true><<<nb, MD_BLOCK, 0, c->stream>>>(n, s, dt, thr2, c->scal.p, step);
+        else
+            k_kickdrift<2, false><<<nb, MD_BLOCK, 0, c->stream>>>(n, s, dt, thr2, c->scal.p, step);
+    }
+}
+
+void launch_ghost_update(md_ctx *c, int step)
+{
+    if (c->nghost == 0) return;
+    DevState s = c->dev(c->cur);
+    int nb = nblocks(c->nghost);
+    if (c->dim == 3)
+        k_ghost_update<3><<<nb, MD_BLOCK, 0, c->stream>>>((int)c->n, (int)c->nghost, s, c->grid, c->gowner.p,
+                                                          c->gcode.p, c->scal.p, step);
+    else
+        k_ghost_update<2><<<nb, MD_BLOCK, 0, c->stream>>>((int)c->n, (int)c->nghost, s, c->grid, c->gowner.p,
+                                                          c->gcode.p, c->scal.p, step);
+}
+
+void launch_finalize(md_ctx *c, bool want_uw, bool nvt, double nf, double term1, int step)
+{
+    k_finalize<<<1, 1024, 0, c->stream>>>(c->nblk, c->partials.p, want_uw ? 1 : 0, nvt ? 1 : 0, nf, term1, c->d_kt.p,
+                                          c->d_r1.p, c->d_r2.p, c->scal.p, step);
+}
+
+Scalars read_scalars(md_ctx *c)
+{
+    Scalars h;
+    HIPCHK(hipMemcpyAsync(&h, c->scal.p, sizeof(Scalars), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return h;
+}
+
+int fail(md_ctx *c, const char *what)
+{
+    if (c)
+        c->err = what;
+    else
+        g_create_error = what;
+    return 1;
+}
+
+} // namespace
+
+#define API_BEGIN                                                                                                   \
+    if (!ctx) return fail(nullptr, "null handle");                                                                  \
+    try {                                                                                                           \
+        HIPCHK(hipSetDevice(ctx->device));
+#define API_END                                                                                                     \
+    }                                                                                                               \
+    catch (const std::exception &e) { return fail(ctx, e.what()); }                                                 \
+    catch (...) { return fail(ctx, "unknown C++ exception"); }                                                      \
+    return 0;
+
+extern "C" {
+
+const char *md_version(void) { return "mdhip 0.1 gfx950"; }
+
+const char *md_last_error(md_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int md_create(int dim, int64_t n_particles, const double *box, double list_cutoff, int device_id, md_ctx **out)
+{
+    if (!out) return fail(nullptr, "md_create: out is null");
+    *out = nullptr;
+    if (dim != 2 && dim != 3) return fail(nullptr, "md_create: dim must be 2 or 3");
+    if (n_particles < 2) return fail(nullptr, "md_create: need at least 2 particles");
+    if (n_particles >= (int64_t)MD_VAL_SRC_MASK) return fail(nullptr, "md_create: too many particles for one handle (limit 2^26-1)");
+    if (!box) return fail(nullptr, "md_create: box is null");
+    if (!(list_cutoff > 0.0)) return fail(nullptr, "md_create: list_cutoff must be positive");
+    for (int r = 0; r < dim; ++r)
+        for (int c = 0; c < dim; ++c) {
+            double v = box[c * dim + r];
+            if (r != c && v != 0.0)
+                return fail(nullptr, "md_create: only orthorhombic (diagonal) unit cells are supported in this version");
+            if (r == c && !(v > 0.0)) return fail(nullptr, "md_create: box lengths must be positive");
+        }
+    md_ctx *ctx = nullptr;
+    try {
+        int ndev = 0;
+        hipError_t e = hipGetDeviceCount(&ndev);
+        if (e != hipSuccess || ndev == 0) return fail(nullptr, "md_create: no HIP device available (libmdhip has no CPU fallback)");
+        ctx = new md_ctx();
+        if (device_id < 0) HIPCHK(hipGetDevice(&device_id));
+        if (device_id >= ndev) throw HipError("md_create: device_id out of range");
+        ctx->device = device_id;
+        HIPCHK(hipSetDevice(device_id));
+        HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        ctx->dim = dim;
+        ctx->n = n_particles;
+        for (int c = 0; c < dim; ++c) ctx->L[c] = box[c * dim + c];
+        ctx->rc = list_cutoff;
+        // default potential: LennardJones() -- src/potentials.jl:52-64
+        ctx->pot_kind = POT_LJ;
+        ctx->pp.p[0] = 1.0;
+        ctx->pp.p[1] = 1.0;
+        ctx->pp.p[2] = 2.5;
+        configure_grid(ctx);
+        configure_potential(ctx);
+        // capacity: owned + ghost shell estimate
+        double frac = 1.0;
+        for (int c = 0; c < dim; ++c) frac *= (double)ctx->grid.ncx[c] / ctx->grid.nc[c];
+        int64_t gcap = (int64_t)((frac - 1.0) * 1.3 * n_particles) + 4096;
+        ctx->cap = n_particles + gcap;
+        alloc_state(ctx, 0, ctx->cap);
+        alloc_state(ctx, 1, ctx->cap);
+        int64_t n = n_particles;
+        ctx->nimg.alloc(n + 1);
+        ctx->img_off.alloc(n + 1);
+        HIPCHK(hipMemsetAsync(ctx->nimg.p, 0, sizeof(int32_t) * (n + 1), ctx->stream));
+        ctx->newslot.alloc(n);
+        ctx->keys_in.alloc(ctx->cap);
+        ctx->keys_out.alloc(ctx->cap);
+        ctx->vals_in.alloc(ctx->cap);
+        ctx->vals_out.alloc(ctx->cap);
+        ctx->gsrc.alloc(gcap + 1);
+        ctx->gcode.alloc(gcap + 1);
+        ctx->gowner.alloc(gcap + 1);
+        ctx->nblk = nblocks(n);
+        ctx->ntiles = (int64_t)ctx->nblk * (MD_BLOCK / 64);
+        ctx->nneigh.alloc(n);
+        ctx->nmax_tile.alloc(ctx->ntiles);
+        // expected neighbours within rc+skin at this density, with headroom
+        double dens = (double)n;
+        for (int c = 0; c < dim; ++c) dens /= ctx->L[c];
+        double vol = (dim == 3) ? 4.18879020478639 * ctx->rl * ctx->rl * ctx->rl : 3.14159265358979 * ctx->rl * ctx->rl;
+        int maxn = (int)(dens * vol * 1.35) + 24;
+        ctx->maxn = (maxn + 3) & ~3;
+        ctx->nlist.alloc((size_t)ctx->ntiles * ctx->maxn * 64);
+        ctx->partials.alloc((size_t)3 * ctx->nblk);
+        HIPCHK(hipMemsetAsync(ctx->partials.p, 0, sizeof(double) * 3 * ctx->nblk, ctx->stream));
+        ctx->scal.alloc(1);
+        Scalars h{};
+        h.scale = 1.0;
+        h.first_viol = MD_NO_VIOLATION;
+        HIPCHK(hipMemcpyAsync(ctx->scal.p, &h, sizeof h, hipMemcpyHostToDevice, ctx->stream));
+        ctx->d_kt.alloc(1);
+        ctx->d_r1.alloc(1);
+        ctx->d_r2.alloc(1);
+        for (int w = 0; w < 2; ++w)
+            k_init_state<<<nblocks(ctx->cap + 1), MD_BLOCK, 0, ctx->stream>>>((int)n, ctx->cap, ctx->dev(w), dim);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    } catch (const std::exception &e) {
+        g_create_error = e.what();
+        delete ctx;
+        return 1;
+    }
+    *out = ctx;
+    return 0;
+}
+
+int md_destroy(md_ctx *ctx)
+{
+    if (!ctx) return 0;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamDestroy(ctx->stream);
+    }
+    for (auto &p : ctx->prof_ev) {
+        (void)hipEventDestroy(p.first);
+        (void)hipEventDestroy(p.second);
+    }
+    delete ctx;
+    return 0;
+}
+
+int md_set_potential(md_ctx *ctx, int kind, const double *params, int nparams)
+{
+    API_BEGIN
+    if (kind != MD_POT_LJ && kind != MD_POT_PSEUDOHS && kind != MD_POT_POLYDISPERSE)
+        throw HipError("md_set_potential: unknown potential kind");
+    if (nparams < 0 || nparams > 8 || (nparams > 0 && !params)) throw HipError("md_set_potential: bad params");
+    int need = (kind == MD_POT_LJ) ? 3 : (kind == MD_POT_PSEUDOHS ? 1 : 2);
+    if (nparams < need) throw HipError("md_set_potential: too few parameters for this kind");
+    for (int i = 0; i < 8; ++i) ctx->pp.p[i] = (i < nparams) ? params[i] : 0.0;
+    ctx->pot_kind = kind;
+    configure_potential(ctx);
+    API_END
+}
+
+int md_set_potential_source(md_ctx *ctx, const char *hip_src, const char *entry_name, const double *params,
+                            int nparams)
+{
+    API_BEGIN
+    (void)hip_src;
+    (void)entry_name;
+    (void)params;
+    (void)nparams;
+    throw HipError("md_set_potential_source: run-time compiled potentials are not available in this build");
+    API_END
+}
+
+int md_set_skin(md_ctx *ctx, double skin)
+{
+    API_BEGIN
+    if (!(skin >= 0.0)) throw HipError("md_set_skin: skin must be >= 0");
+    ctx->skin_req = skin;
+    double old_rl = ctx->rl;
+    configure_grid(ctx);
+    if (ctx->rl > old_rl) {
+        double dens = (double)ctx->n;
+        for (int c = 0; c < ctx->dim; ++c) dens /= ctx->L[c];
+        double vol = (ctx->dim == 3) ? 4.18879020478639 * ctx->rl * ctx->rl * ctx->rl
+                                     : 3.14159265358979 * ctx->rl * ctx->rl;
+        int maxn = ((int)(dens * vol * 1.35) + 24 + 3) & ~3;
+        if (maxn > ctx->maxn) {
+            ctx->maxn = maxn;
+            ctx->nlist.alloc((size_t)ctx->ntiles * ctx->maxn * 64);
+        }
+    }
+    ctx->target_interval = 8;
+    API_END
+}
+
+int md_upload(md_ctx *ctx, const double *x, const double *v, const double *f, const int32_t *images,
+              const double *diameters)
+{
+    API_BEGIN
+    size_t nd = (size_t)ctx->n * ctx->dim;
+    hipStream_t st = ctx->stream;
+    if (x) {
+        ctx->io_x.ensure(nd);
+        HIPCHK(hipMemcpyAsync(ctx->io_x.p, x, nd * sizeof(double), hipMemcpyHostToDevice, st));
+    }
+    if (v) {
+        ctx->io_v.ensure(nd);
+        HIPCHK(hipMemcpyAsync(ctx->io_v.p, v, nd * sizeof(double), hipMemcpyHostToDevice, st));
+    }
+    if (f) {
+        ctx->io_f.ensure(nd);
+        HIPCHK(hipMemcpyAsync(ctx->io_f.p, f, nd * sizeof(double), hipMemcpyHostToDevice, st));
+    }
+    if (images) {
+        ctx->io_i.ensure(nd);
+        HIPCHK(hipMemcpyAsync(ctx->io_i.p, images, nd * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    }
+    if (diameters) {
+        ctx->io_d.ensure(ctx->n);
+        HIPCHK(hipMemcpyAsync(ctx->io_d.p, diameters, ctx->n * sizeof(double), hipMemcpyHostToDevice, st));
+        bool uni = true;
+        for (int64_t i = 1; i < ctx->n; ++i)
+            if (diameters[i] != diameters[0]) {
+                uni = false;
+                break;
+            }
+        ctx->uniform_sigma = uni;
+        ctx->sigma_u = diameters[0];
+        configure_potential(ctx);
+    }
+    DevState s = ctx->dev(ctx->cur);
+    int nb = ctx->nblk;
+    if (ctx->dim == 3)
+        k_import<3><<<nb, MD_BLOCK, 0, st>>>((int)ctx->n, s, x ? ctx->io_x.p : nullptr, v ? ctx->io_v.p : nullptr,
+                                             f ? ctx->io_f.p : nullptr, images ? ctx->io_i.p : nullptr,
+                                             diameters ? ctx->io_d.p : nullptr);
+    else
+        k_import<2><<<nb, MD_BLOCK, 0, st>>>((int)ctx->n, s, x ? ctx->io_x.p : nullptr, v ? ctx->io_v.p : nullptr,
+                                             f ? ctx->io_f.p : nullptr, images ? ctx->io_i.p : nullptr,
+                                             diameters ? ctx->io_d.p : nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st)); // host buffers are only borrowed for this call
+    if (x || diameters) ctx->list_valid = false;
+    API_END
+}
+
+int md_download(md_ctx *ctx, double *x, double *v, double *f, int32_t *images)
+{
+    API_BEGIN
+    size_t nd = (size_t)ctx->n * ctx->dim;
+    hipStream_t st = ctx->stream;
+    ctx->io_x.ensure(nd);
+    ctx->io_v.ensure(nd);
+    ctx->io_f.ensure(nd);
+    ctx->io_i.ensure(nd);
+    DevState s = ctx->dev(ctx->cur);
+    int nb = ctx->nblk;
+    if (ctx->dim == 3)
+        k_export<3><<<nb, MD_BLOCK, 0, st>>>((int)ctx->n, s, ctx->grid, ctx->io_x.p, ctx->io_v.p, ctx->io_f.p, ctx->io_i.p);
+    else
+        k_export<2><<<nb, MD_BLOCK, 0, st>>>((int)ctx->n, s, ctx->grid, ctx->io_x.p, ctx->io_v.p, ctx->io_f.p, ctx->io_i.p);
+    HIPCHK(hipGetLastError());
+    if (x) HIPCHK(hipMemcpyAsync(x, ctx->io_x.p, nd * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (v) HIPCHK(hipMemcpyAsync(v, ctx->io_v.p, nd * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (f) HIPCHK(hipMemcpyAsync(f, ctx->io_f.p, nd * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (images) HIPCHK(hipMemcpyAsync(images, ctx->io_i.p, nd * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    API_END
+}
+
+int md_compute_forces(md_ctx *ctx, double *energy, double *virial)
+{
+    API_BEGIN
+    if (!ctx->list_valid) rebuild(ctx);
+    launch_force(ctx, true, false, 0.0, -1);
+    launch_finalize(ctx, true, false, 1.0, 0.0, -1);
+    HIPCHK(hipGetLastError());
+    Scalars h = read_scalars(ctx);
+    if (energy) *energy = h.U;
+    if (virial) *virial = h.W;
+    API_END
+}
+
+int md_neighbor_pairs(md_ctx *ctx, int32_t *pairs, int64_t cap, int64_t *count)
+{
+    API_BEGIN
+    if (cap < 0 || (cap > 0 && !pairs)) throw HipError("md_neighbor_pairs: bad output buffer");
+    if (!ctx->list_valid) rebuild(ctx);
+    hipStream_t st = ctx->stream;
+    DBuf<int32_t> out;
+    out.alloc((size_t)std::max<int64_t>(cap, 1) * 2);
+    unsigned long long zero = 0;
+    HIPCHK(hipMemcpyAsync(&ctx->scal.p->pair_count, &zero, sizeof zero, hipMemcpyHostToDevice, st));
+    DevState s = ctx->dev(ctx->cur);
+    double c2 = ctx->rc * ctx->rc;
+    if (ctx->dim == 3)
+        k_pairs<3><<<ctx->nblk, MD_BLOCK, 0, st>>>((int)ctx->n, s, c2, ctx->nlist.p, ctx->maxn, ctx->nneigh.p, out.p,
+                                                   (unsigned long long)cap, ctx->scal.p);
+    else
+        k_pairs<2><<<ctx->nblk, MD_BLOCK, 0, st>>>((int)ctx->n, s, c2, ctx->nlist.p, ctx->maxn, ctx->nneigh.p, out.p,
+                                                   (unsigned long long)cap, ctx->scal.p);
+    HIPCHK(hipGetLastError());
+    Scalars h = read_scalars(ctx);
+    int64_t found = (int64_t)h.pair_count;
+    if (count) *count = found;
+    int64_t ncopy = std::min(found, cap);
+    if (ncopy > 0) {
+        HIPCHK(hipMemcpyAsync(pairs, out.p, (size_t)ncopy * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    API_END
+}
+
+int md_run(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, double tau, double nf, const double *ktemp,
+           const double *r1, const double *r2, double *uwk)
+{
+    API_BEGIN
+    if (nsteps < 0) throw HipError("md_run: nsteps must be >= 0");
+    if (nsteps > 0x3fffffff) throw HipError("md_run: nsteps too large for one call");
+    if (ensemble != MD_NVE && ensemble != MD_NVT) throw HipError("md_run: unknown ensemble");
+    bool nvt = ensemble == MD_NVT;
+    if (nvt && (!ktemp || !r1 || !r2)) throw HipError("md_run: NVT needs ktemp, r1 and r2 arrays");
+    if (nvt && !(tau > 0.0)) throw HipError("md_run: NVT needs tau > 0");
+    if (nsteps == 0) {
+        if (uwk) uwk[0] = uwk[1] = uwk[2] = NAN;
+        return 0;
+    }
+    hipStream_t st = ctx->stream;
+    double term1 = 0.0;
+    if (nvt) {
+        ctx->d_kt.ensure(nsteps);
+        ctx->d_r1.ensure(nsteps);
+        ctx->d_r2.ensure(nsteps);
+        HIPCHK(hipMemcpyAsync(ctx->d_kt.p, ktemp, nsteps * sizeof(double), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(ctx->d_r1.p, r1, nsteps * sizeof(double), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(ctx->d_r2.p, r2, nsteps * sizeof(double), hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+        term1 = std::exp(-(dt / tau));
+    }
+    if (!ctx->list_valid) rebuild(ctx);
+    bool want = uwk != nullptr;
+    auto force_part = [&](int t) {
+        bool last = (t == (int)nsteps - 1);
+        bool uw = last && want;
+        launch_force(ctx, uw, true, dt, t);
+        if (nvt || uw) launch_finalize(ctx, uw, nvt, nf, term1, t);
+    };
+    if (ctx->skin <= 0.0) {
+        // literal reference cadence: a fresh linked-cell build every step
+        for (int t = 0; t < (int)nsteps; ++t) {
+            launch_kickdrift(ctx, nvt, dt, INFINITY, t);
+            rebuild(ctx);
+            force_part(t);
+        }
+    } else {
+        double thr2 = (0.5 * ctx->skin) * (0.5 * ctx->skin);
+        int s = 0;
+        while (s < (int)nsteps) {
+            int64_t room = std::max<int64_t>(1, ctx->target_interval - ctx->steps_since_build);
+            int chunk_end = (int)std::min<int64_t>(nsteps, (int64_t)s + room);
+            for (int t = s; t < chunk_end; ++t) {
+                launch_kickdrift(ctx, nvt, dt, thr2, t);
+                launch_ghost_update(ctx, t);
+                force_part(t);
+            }
+            HIPCHK(hipGetLastError());
+            Scalars h = read_scalars(ctx);
+            if (h.first_viol < chunk_end) {
+                // some particle moved skin/2 during step m's drift: everything from its force
+                // evaluation on was skipped on the device.  Rebuild at the drifted positions
+                // and resume with the force half of step m.
+                int m = h.first_viol;
+                ctx->st_viol++;
+                int64_t observed = ctx->steps_since_build + (m - s) + 1;
+                ctx->target_interval = std::max<int64_t>(2, (observed * 4) / 5);
+                rebuild(ctx);
+                force_part(m);
+                s = m + 1;
+            } else {
+                ctx->steps_since_build += chunk_end - s;
+                s = chunk_end;
+                if (s < (int)nsteps && ctx->steps_since_build >= ctx->target_interval) {
+                    // scheduled rebuild just ahead of the expected violation; creep the
+                    // interval up so it tracks the true one from below
+                    rebuild(ctx);
+                    ctx->target_interval += 1;
+                }
+            }
+        }
+    }
+    if (nvt) {
+        // apply the last step's pending rescale (src/thermostat.jl:43-45) so the state the
+        // host can download is the reference's
+        DevState sd = ctx->dev(ctx->cur);
+        if (ctx->dim == 3)
+            k_scale_v<3><<<ctx->nblk, MD_BLOCK, 0, st>>>((int)ctx->n, sd, ctx->scal.p, 1.0, 1);
+        else
+            k_scale_v<2><<<ctx->nblk, MD_BLOCK, 0, st>>>((int)ctx->n, sd, ctx->scal.p, 1.0, 1);
+        k_set_scale<<<1, 1, 0, st>>>(ctx->scal.p, 1.0);
+    }
+    HIPCHK(hipGetLastError());
+    Scalars h = read_scalars(ctx);
+    if (want) {
+        uwk[0] = h.U;
+        uwk[1] = h.W;
+        uwk[2] = h.K;
+    }
+    ctx->st_steps += nsteps;
+    API_END
+}
+
+int md_kinetic(md_ctx *ctx, double *kinetic)
+{
+    API_BEGIN
+    DevState s = ctx->dev(ctx->cur);
+    if (ctx->dim == 3)
+        k_ke_partials<3><<<ctx->nblk, MD_BLOCK, 0, ctx->stream>>>((int)ctx->n, s, ctx->partials.p);
+    else
+        k_ke_partials<2><<<ctx->nblk, MD_BLOCK, 0, ctx->stream>>>((int)ctx->n, s, ctx->partials.p);
+    launch_finalize(ctx, false, false, 1.0, 0.0, -1);
+    HIPCHK(hipGetLastError());
+    Scalars h = read_scalars(ctx);
+    if (kinetic) *kinetic = h.K;
+    API_END
+}
+
+int md_scale_velocities(md_ctx *ctx, double sfac)
+{
+    API_BEGIN
+    DevState s = ctx->dev(ctx->cur);
+    if (ctx->dim == 3)
+        k_scale_v<3><<<ctx->nblk, MD_BLOCK, 0, ctx->stream>>>((int)ctx->n, s, ctx->scal.p, sfac, 0);
+    else
+        k_scale_v<2><<<ctx->nblk, MD_BLOCK, 0, ctx->stream>>>((int)ctx->n, s, ctx->scal.p, sfac, 0);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    API_END
+}
+
+int md_profile(md_ctx *ctx, int enable)
+{
+    API_BEGIN
+    prof_collect(ctx);
+    ctx->prof = enable != 0;
+    if (enable) {
+        ctx->prof_ms_acc = 0.0;
+        ctx->prof_launch_acc = 0;
+    }
+    API_END
+}
+
+int md_get_stats(md_ctx *ctx, md_stats *out)
+{
+    API_BEGIN
+    if (!out) throw HipError("md_get_stats: out is null");
+    prof_collect(ctx);
+    out->steps = ctx->st_steps;
+    out->rebuilds = ctx->st_rebuilds;
+    out->violations = ctx->st_viol;
+    out->n_ghost = ctx->nghost;
+    out->max_neighbors = ctx->maxn;
+    out->avg_neighbors = 0.0;
+    if (ctx->list_valid) {
+        std::vector<int32_t> h((size_t)ctx->n);
+        HIPCHK(hipMemcpyAsync(h.data(), ctx->nneigh.p, sizeof(int32_t) * ctx->n, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        double sum = 0.0;
+        for (int32_t v : h) sum += v;
+        out->avg_neighbors = sum / (double)ctx->n;
+    }
+    out->force_launches = ctx->prof_launch_acc;
+    out->force_ms = ctx->prof_ms_acc;
+    API_END
+}
+
+} // extern "C"

@@ -1,0 +1,102 @@
+"""run_simulation! -- src/simulation.jl:40-178 (the NVE/NVT method).
+
+The step loop itself runs device-resident inside libmdhip (md_run); this driver only cuts the
+run into segments that end on the reference's output steps (step % frequency == 0, 0-based,
+so step 0 is always an output step), draws the thermostat's random numbers on the host in the
+reference's order, and writes the thermo / trajectory files.
+"""
+import os
+
+import numpy as np
+
+from . import _lib
+from . import io as _io
+from .thermostat import draw_bussi
+from .types import NVE, NVT, Brownian
+
+
+def compute_box_volume(unitcell):
+    """src/simulation.jl:7-9"""
+    return abs(float(np.linalg.det(np.asarray(unitcell))))
+
+
+def _configure_device(state, params):
+    dev = state.system.device
+    spec = params.potential.device_spec()
+    if spec[0] == "builtin":
+        dev.set_potential(spec[1], spec[2])
+    elif spec[0] == "source":
+        dev.set_potential_source(spec[1], spec[2], spec[3] if len(spec) > 3 else ())
+    else:
+        raise ValueError("device_spec() must return ('builtin', kind, params) or ('source', src, entry, params)")
+    return dev
+
+
+def run_simulation(state, params, ensemble, total_steps, frequency, pathname, traj_name="trajectory.xyz",
+                   thermo_name="thermo.txt", compress=False, log_times=False, write_trajectory=True):
+    """Python spelling of run_simulation! (mutates `state`, returns None)."""
+    if isinstance(ensemble, Brownian):
+        raise NotImplementedError("Brownian dynamics is out of scope (broken in the reference, SURVEY.md D9)")
+    if log_times:
+        raise NotImplementedError("log-spaced snapshots (src/simulation.jl:153-171) are not provided")
+    if compress:
+        raise NotImplementedError("zstd compression (src/io.jl:207-223) is not provided in this image")
+    os.makedirs(pathname, exist_ok=True)
+    trajectory_file, thermo_file = _io.open_files(pathname, traj_name, thermo_name)
+    with open(thermo_file, "a") as io:
+        io.write("# Step Energy Temperature Pressure\n")
+
+    dev = _configure_device(state, params)
+    dim = state.dimension
+    n = params.n_particles
+    pot = params.potential
+    volume = compute_box_volume(state.unitcell)
+    if state.velocities is None or len(state.velocities) != n:
+        raise ValueError("state.velocities must be set before run_simulation (README.md:39-41)")
+    # the host-side state is the truth at entry, exactly as in the reference
+    dev.upload(x=state.system.positions, v=state.velocities, f=state.system.energy_and_forces.forces,
+               images=state.images, diameters=state.diameters)
+
+    nvt = isinstance(ensemble, NVT)
+    ens_kind = _lib.MD_NVT if nvt else _lib.MD_NVE
+    tau = ensemble.tau if nvt else 0.0
+
+    def segment(first_step, nsteps):
+        kt = r1 = r2 = None
+        if nvt:
+            # ensemble_step! receives step+1 (src/simulation.jl:108)
+            kt = np.array([ensemble.ktemp(s + 1) for s in range(first_step, first_step + nsteps)], dtype=np.float64)
+            r1, r2 = draw_bussi(state.nf, state.rng, nsteps)
+        return dev.run(nsteps, params.dt, ens_kind, tau, state.nf, kt, r1, r2, thermo=True)
+
+    step = 0
+    while step < total_steps:
+        # run up to and including the next output step
+        next_out = step if step % frequency == 0 else (step // frequency + 1) * frequency
+        last = min(next_out, total_steps - 1)
+        U, W, K = segment(step, last - step + 1)
+        step = last + 1
+        if last % frequency == 0:
+            temperature = 2.0 * K / state.nf
+            total_energy = (U + pot.energy_lrc(n, volume)) / n          # src/simulation.jl:433-437
+            pressure = W / (dim * volume) + params.rho * temperature    # :441-442
+            pressure += pot.pressure_lrc(n, volume)                     # :444
+            with open(thermo_file, "a") as io:
+                io.write("%d %.6f %.6f %.6f\n" % (last, total_energy, temperature, pressure))
+            state.system.energy_and_forces.energy = U
+            state.system.energy_and_forces.virial = W
+            if write_trajectory:
+                x, _, _, img = dev.download()
+                _io.write_to_file_lammps(trajectory_file, last, state.unitcell, n, x, img, state.diameters, dim,
+                                         mode="a")
+
+    x, v, f, img = dev.download()
+    state.system.positions = x
+    state.system.xpositions = x
+    state.velocities = v
+    state.images = img
+    state.system.energy_and_forces.forces = f
+    # finalize_simulation!: src/simulation.jl:11-36
+    _io.write_to_file(os.path.join(pathname, "final.xyz"), total_steps, state.unitcell, n, x, state.diameters, dim,
+                      mode="w")
+    return None

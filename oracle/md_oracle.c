@@ -1,0 +1,574 @@
+/*
+ * md_oracle.c -- CPU restatement of MolecularDynamics.jl's force + velocity-Verlet +
+ * thermostat path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load this library; the product (moleculardynamics/jl_amd) never
+ * does.
+ *
+ * PARITY UNPINNED: the reference ships no tests, fixtures or golden vectors, is Julia
+ * (no interpreter in the build image) and delegates pair enumeration to CellListMap.jl,
+ * which is neither vendored nor version-pinned (Project.toml:7, no [compat] entry).  This
+ * file therefore restates the reference's arithmetic from its source text, and restates
+ * CellListMap's published algorithm (periodic images as translated ghost copies, every
+ * unordered pair visited once, accepted iff d^2 <= cutoff^2).  It is checked against the
+ * analytic known-answer values derived from the reference formulas.
+ *
+ * Reference lines each function follows are cited as  file:line  into /root/reference.
+ *
+ * Layout at this boundary is the reference's: column-major d x N matrices, i.e. particle
+ * i's component c lives at a[i*d + c] (what a Julia Matrix{Float64}(d,N) or a
+ * Vector{MVector{d}} packed contiguously looks like).
+ *
+ * Canonical pair geometry (shared bit-for-bit with the HIP path):
+ *   for the ordered pair (a -> b), per component c:
+ *     d0 = x_b - x_a ; s = (d0 > L/2) ? -1 : (d0 < -L/2) ? +1 : 0
+ *     xb' = x_b + s*L          (the translated ghost copy, rounded once)
+ *     del = xb' - x_a
+ *   d2 = fma(del_z,del_z, fma(del_y,del_y, del_x*del_x))      (3-D)
+ *   d2 = fma(del_y,del_y, del_x*del_x)                         (2-D)
+ * The unordered pair {i,j} is oriented a=min(i,j), b=max(i,j).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define POT_LJ 0
+#define POT_PSEUDOHS 1
+#define POT_POLYDISPERSE 2
+
+typedef struct {
+    int kind;
+    double p[8];
+} oracle_pot;
+
+/* ---------------------------------------------------------------- potentials */
+
+/* src/potentials.jl:66-77 (lj_unshifted under @fastpow: integer powers are multiply chains) */
+static inline void lj_unshifted(double r, double eps, double sigma, double r_cut, double *u, double *f)
+{
+    if (r >= r_cut) {
+        *u = 0.0;
+        *f = 0.0;
+        return;
+    }
+    double sr = sigma / r;
+    double sr2 = sr * sr;
+    double sr6 = (sr2 * sr2) * sr2;
+    double sr12 = sr6 * sr6;
+    *u = (4.0 * eps) * (sr12 - sr6);
+    *f = ((24.0 * eps) * (2.0 * sr12 - sr6)) / r;
+}
+
+/* src/potentials.jl:1-3,16-29 (lambda is a Float64 keyword => generic pow) */
+static const double b_param = 1.0204081632653061;
+static const double a_param = 134.5526623421209;
+static inline void pseudohs(double rij, double sigma, double lambda, double *u, double *f)
+{
+    double uij = 0.0, fij = 0.0;
+    if (rij < b_param) {
+        uij = a_param * (pow(sigma / rij, lambda) - pow(sigma / rij, lambda - 1.0));
+        uij += 1.0;
+        fij = lambda * pow(sigma / rij, lambda + 1.0);
+        fij -= (lambda - 1.0) * pow(sigma / rij, lambda);
+        fij *= a_param;
+    }
+    *u = uij;
+    *f = fij;
+}
+
+static inline double ipow(double x, int n)
+{
+    double r = 1.0;
+    while (n) {
+        if (n & 1) r *= x;
+        x *= x;
+        n >>= 1;
+    }
+    return r;
+}
+
+/* README.md:89-118 (poly_potential) */
+static inline void poly_potential(double r, double sigma, double r_cut, double *u, double *f)
+{
+    double uij = 0.0, fij = 0.0;
+    if (r < r_cut * sigma) {
+        double term_1 = ipow(sigma / r, 12);
+        double c0 = -28.0 / ipow(r_cut, 12);
+        double c2 = 48.0 / ipow(r_cut, 14);
+        double c4 = -21.0 / ipow(r_cut, 16);
+        double term_2 = c2 * ipow(r / sigma, 2);
+        double term_3 = c4 * ipow(r / sigma, 4);
+        uij = term_1 + c0 + term_2 + term_3;
+        fij = 12.0 * ipow(sigma, 12) / ipow(r, 13) - 2.0 * c2 * r / ipow(sigma, 2) -
+              4.0 * c4 * ipow(r, 3) / ipow(sigma, 4);
+    }
+    *u = uij;
+    *f = fij;
+}
+
+/* The plugin contract: evaluate(pot, r, sigma1, sigma2) -> (u, f), f = -dU/dr.
+ * src/pairwise.jl:31 (positional 4-arg call); src/potentials.jl:11-14,160-164; README.md:132-145 */
+void oracle_evaluate(const oracle_pot *pot, double r, double s1, double s2, double *u, double *f)
+{
+    switch (pot->kind) {
+    case POT_LJ: {
+        double sigma = (s1 + s2) / 2.0;
+        lj_unshifted(r, pot->p[0], sigma, pot->p[2], u, f);
+        break;
+    }
+    case POT_PSEUDOHS: {
+        double sigma = (s1 + s2) / 2.0;
+        pseudohs(r, sigma, pot->p[0], u, f);
+        break;
+    }
+    case POT_POLYDISPERSE: {
+        double se = 0.5 * (s1 + s2);
+        se *= (1.0 - pot->p[1] * fabs(s1 - s2));
+        poly_potential(r, se, pot->p[0], u, f);
+        break;
+    }
+    default:
+        *u = NAN;
+        *f = NAN;
+    }
+}
+
+/* src/potentials.jl:111-128 */
+double oracle_ener_lrc(double cutoff, double density, double sigma)
+{
+    double uij = (ipow(sigma / cutoff, 9) / 3.0) - ipow(sigma / cutoff, 3);
+    uij *= 8.0 * M_PI * density / 3.0;
+    return uij;
+}
+double oracle_pressure_lrc(double cutoff, double density, double sigma)
+{
+    double sr3 = ipow(sigma / cutoff, 3);
+    double result = (2.0 * ipow(sr3, 3) / 3.0) - sr3;
+    result *= 16.0 * M_PI * density * density / 3.0;
+    return result;
+}
+
+/* ---------------------------------------------------------------- pair geometry */
+
+static inline double canon_d2(int dim, const double *xa, const double *xb, const double *L, double *del)
+{
+    del[0] = del[1] = del[2] = 0.0;
+    for (int c = 0; c < dim; ++c) {
+        double d0 = xb[c] - xa[c];
+        double half = 0.5 * L[c];
+        double s = (d0 > half) ? -1.0 : ((d0 < -half) ? 1.0 : 0.0);
+        double xbp = xb[c] + s * L[c];
+        del[c] = xbp - xa[c];
+    }
+    double d2 = del[0] * del[0];
+    d2 = fma(del[1], del[1], d2);
+    if (dim == 3) d2 = fma(del[2], del[2], d2);
+    return d2;
+}
+
+typedef struct {
+    double energy, virial;
+    double *forces;
+} enf_t;
+
+/* src/pairwise.jl:26-39 energy_and_forces!  (x is particle i's coordinate, y is j's
+ * translated image; r = x - y).  a<b orientation: x = x_a, y = x_b'. */
+static inline void pair_update(int dim, int a, int b, const double *del_ab, double d2, const double *diam,
+                               const oracle_pot *pot, enf_t *out)
+{
+    double d = sqrt(d2);
+    double u, fij;
+    oracle_evaluate(pot, d, diam[a], diam[b], &u, &fij);
+    double dotv = 0.0;
+    double s[3];
+    for (int c = 0; c < dim; ++c) {
+        double r = -del_ab[c]; /* x_a - x_b' */
+        s[c] = fij * r / d;
+        dotv += s[c] * r;
+    }
+    out->virial += dotv;
+    out->energy += u;
+    for (int c = 0; c < dim; ++c) {
+        out->forces[a * dim + c] += s[c];
+        out->forces[b * dim + c] -= s[c];
+    }
+}
+
+/* Serial sum over unordered pairs i<j ascending: the only mode in which the reference is
+ * sound.  O(N^2).  Optionally records the accepted pairs. */
+int64_t oracle_forces_brute(int dim, int n, const double *x, const double *L, double cutoff, const oracle_pot *pot,
+                            const double *diam, double *forces, double *energy, double *virial, int32_t *pairs,
+                            int64_t pair_cap)
+{
+    enf_t out;
+    out.energy = 0.0;
+    out.virial = 0.0;
+    out.forces = forces;
+    memset(forces, 0, sizeof(double) * (size_t)n * dim); /* src/pairwise.jl:6-15 reset_output! */
+    double c2 = cutoff * cutoff;
+    int64_t np = 0;
+    for (int i = 0; i < n; ++i) {
+        for (int j = i + 1; j < n; ++j) {
+            double del[3];
+            double d2 = canon_d2(dim, x + (size_t)i * dim, x + (size_t)j * dim, L, del);
+            if (d2 <= c2) {
+                pair_update(dim, i, j, del, d2, diam, pot, &out);
+                if (pairs && np < pair_cap) {
+                    pairs[2 * np] = i;
+                    pairs[2 * np + 1] = j;
+                }
+                ++np;
+            }
+        }
+    }
+    *energy = out.energy;
+    *virial = out.virial;
+    return np;
+}
+
+/* ---------------------------------------------------------------- linked cells (CPU) */
+
+typedef struct {
+    int nc[3];
+    int ncell;
+    int *start; /* ncell+1 */
+    int *items; /* n, particle ids sorted by cell, ascending id inside a cell */
+} cells_t;
+
+static int cells_build(cells_t *cl, int dim, int n, const double *x, const double *L, double cutoff)
+{
+    cl->ncell = 1;
+    for (int c = 0; c < 3; ++c) cl->nc[c] = 1;
+    for (int c = 0; c < dim; ++c) {
+        int k = (int)floor(L[c] / cutoff);
+        if (k < 3) return -1;
+        cl->nc[c] = k;
+        cl->ncell *= k;
+    }
+    cl->start = (int *)calloc((size_t)cl->ncell + 1, sizeof(int));
+    cl->items = (int *)malloc(sizeof(int) * (size_t)n);
+    int *cid = (int *)malloc(sizeof(int) * (size_t)n);
+    for (int i = 0; i < n; ++i) {
+        int idx[3] = {0, 0, 0};
+        for (int c = 0; c < dim; ++c) {
+            /* positions may sit a hair outside [0,L): wrap the cell index */
+            double fr = x[(size_t)i * dim + c] / L[c];
+            fr -= floor(fr);
+            int k = (int)(fr * cl->nc[c]);
+            if (k >= cl->nc[c]) k = cl->nc[c] - 1;
+            if (k < 0) k = 0;
+            idx[c] = k;
+        }
+        cid[i] = (idx[2] * cl->nc[1] + idx[1]) * cl->nc[0] + idx[0];
+        cl->start[cid[i] + 1]++;
+    }
+    for (int c = 0; c < cl->ncell; ++c) cl->start[c + 1] += cl->start[c];
+    int *fill = (int *)malloc(sizeof(int) * (size_t)cl->ncell);
+    memcpy(fill, cl->start, sizeof(int) * (size_t)cl->ncell);
+    for (int i = 0; i < n; ++i) cl->items[fill[cid[i]]++] = i;
+    free(fill);
+    free(cid);
+    return 0;
+}
+static void cells_free(cells_t *cl)
+{
+    free(cl->start);
+    free(cl->items);
+}
+
+static inline int wrapi(int k, int n)
+{
+    return k < 0 ? k + n : (k >= n ? k - n : k);
+}
+
+/* Half-shell traversal: every unordered pair once (CellListMap semantics restated), forces
+ * accumulated in per-thread private buffers that are then reduced -- the reference's
+ * copy_output/reducer protocol (src/pairwise.jl:2-4,17-23) done without its aliasing bug. */
+int64_t oracle_forces_cells(int dim, int n, const double *x, const double *L, double cutoff, const oracle_pot *pot,
+                            const double *diam, double *forces, double *energy, double *virial, int nthreads)
+{
+    cells_t cl;
+    if (cells_build(&cl, dim, n, x, L, cutoff) != 0)
+        return oracle_forces_brute(dim, n, x, L, cutoff, pot, diam, forces, energy, virial, NULL, 0);
+    double c2 = cutoff * cutoff;
+#ifdef _OPENMP
+    if (nthreads <= 0) nthreads = omp_get_max_threads();
+#else
+    nthreads = 1;
+#endif
+    double *priv = (double *)calloc((size_t)nthreads * n * dim, sizeof(double));
+    double *e_t = (double *)calloc((size_t)nthreads, sizeof(double));
+    double *w_t = (double *)calloc((size_t)nthreads, sizeof(double));
+    int64_t *np_t = (int64_t *)calloc((size_t)nthreads, sizeof(int64_t));
+    int nzoff = (dim == 3) ? 3 : 1;
+#pragma omp parallel num_threads(nthreads)
+    {
+#ifdef _OPENMP
+        int t = omp_get_thread_num();
+#else
+        int t = 0;
+#endif
+        enf_t out;
+        out.energy = 0.0;
+        out.virial = 0.0;
+        out.forces = priv + (size_t)t * n * dim;
+        int64_t np = 0;
+#pragma omp for schedule(dynamic, 8)
+        for (int cell = 0; cell < cl.ncell; ++cell) {
+            int cx = cell % cl.nc[0];
+            int cy = (cell / cl.nc[0]) % cl.nc[1];
+            int cz = cell / (cl.nc[0] * cl.nc[1]);
+            int s0 = cl.start[cell], e0 = cl.start[cell + 1];
+            for (int oz = 0; oz < nzoff; ++oz) {
+                int dz = (dim == 3) ? oz - 1 : 0;
+                for (int dy = -1; dy <= 1; ++dy) {
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        /* forward half shell: (dz,dy,dx) lexicographically >= 0 */
+                        int code = (dz * 3 + dy) * 3 + dx;
+                        if (code < 0) continue;
+                        int ox = wrapi(cx + dx, cl.nc[0]);
+                        int oy = wrapi(cy + dy, cl.nc[1]);
+                        int ozc = (dim == 3) ? wrapi(cz + dz, cl.nc[2]) : 0;
+                        int other = (ozc * cl.nc[1] + oy) * cl.nc[0] + ox;
+                        int s1 = cl.start[other], e1 = cl.start[other + 1];
+                        for (int p = s0; p < e0; ++p) {
+                            int i = cl.items[p];
+                            int qb = (code == 0) ? p + 1 : s1;
+                            for (int q = qb; q < e1; ++q) {
+                                int j = cl.items[q];
+                                int a = i < j ? i : j, b = i < j ? j : i;
+                                double del[3];
+                                double d2 = canon_d2(dim, x + (size_t)a * dim, x + (size_t)b * dim, L, del);
+                                if (d2 <= c2) {
+                                    pair_update(dim, a, b, del, d2, diam, pot, &out);
+                                    ++np;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        e_t[t] = out.energy;
+        w_t[t] = out.virial;
+        np_t[t] = np;
+    }
+    /* reducer: src/pairwise.jl:17-23 */
+    double e = 0.0, w = 0.0;
+    int64_t np = 0;
+    for (int t = 0; t < nthreads; ++t) {
+        e += e_t[t];
+        w += w_t[t];
+        np += np_t[t];
+    }
+    size_t tot = (size_t)n * dim;
+#pragma omp parallel for num_threads(nthreads)
+    for (size_t k = 0; k < tot; ++k) {
+        double s = 0.0;
+        for (int t = 0; t < nthreads; ++t) s += priv[(size_t)t * tot + k];
+        forces[k] = s;
+    }
+    *energy = e;
+    *virial = w;
+    free(priv);
+    free(e_t);
+    free(w_t);
+    free(np_t);
+    cells_free(&cl);
+    return np;
+}
+
+static int cmp_pair(const void *pa, const void *pb)
+{
+    const int32_t *a = (const int32_t *)pa, *b = (const int32_t *)pb;
+    if (a[0] != b[0]) return a[0] < b[0] ? -1 : 1;
+    if (a[1] != b[1]) return a[1] < b[1] ? -1 : 1;
+    return 0;
+}
+
+/* Canonical sorted pair list (min,max) via linked cells; returns the count (may exceed cap,
+ * in which case only the first cap pairs in traversal order are stored and the list is NOT
+ * sorted -- callers size cap from a first call with cap=0). */
+int64_t oracle_pairs_cells(int dim, int n, const double *x, const double *L, double cutoff, int32_t *pairs,
+                           int64_t cap)
+{
+    cells_t cl;
+    double c2 = cutoff * cutoff;
+    int64_t np = 0;
+    if (cells_build(&cl, dim, n, x, L, cutoff) != 0) {
+        for (int i = 0; i < n; ++i)
+            for (int j = i + 1; j < n; ++j) {
+                double del[3];
+                if (canon_d2(dim, x + (size_t)i * dim, x + (size_t)j * dim, L, del) <= c2) {
+                    if (np < cap) {
+                        pairs[2 * np] = i;
+                        pairs[2 * np + 1] = j;
+                    }
+                    ++np;
+                }
+            }
+        return np;
+    }
+    int nzoff = (dim == 3) ? 3 : 1;
+    for (int cell = 0; cell < cl.ncell; ++cell) {
+        int cx = cell % cl.nc[0];
+        int cy = (cell / cl.nc[0]) % cl.nc[1];
+        int cz = cell / (cl.nc[0] * cl.nc[1]);
+        int s0 = cl.start[cell], e0 = cl.start[cell + 1];
+        for (int oz = 0; oz < nzoff; ++oz) {
+            int dz = (dim == 3) ? oz - 1 : 0;
+            for (int dy = -1; dy <= 1; ++dy)
+                for (int dx = -1; dx <= 1; ++dx) {
+                    int code = (dz * 3 + dy) * 3 + dx;
+                    if (code < 0) continue;
+                    int ox = wrapi(cx + dx, cl.nc[0]);
+                    int oy = wrapi(cy + dy, cl.nc[1]);
+                    int ozc = (dim == 3) ? wrapi(cz + dz, cl.nc[2]) : 0;
+                    int other = (ozc * cl.nc[1] + oy) * cl.nc[0] + ox;
+                    int s1 = cl.start[other], e1 = cl.start[other + 1];
+                    for (int p = s0; p < e0; ++p) {
+                        int i = cl.items[p];
+                        int qb = (code == 0) ? p + 1 : s1;
+                        for (int q = qb; q < e1; ++q) {
+                            int j = cl.items[q];
+                            int a = i < j ? i : j, b = i < j ? j : i;
+                            double del[3];
+                            if (canon_d2(dim, x + (size_t)a * dim, x + (size_t)b * dim, L, del) <= c2) {
+                                if (np < cap) {
+                                    pairs[2 * np] = a;
+                                    pairs[2 * np + 1] = b;
+                                }
+                                ++np;
+                            }
+                        }
+                    }
+                }
+        }
+    }
+    cells_free(&cl);
+    if (np <= cap) qsort(pairs, (size_t)np, 2 * sizeof(int32_t), cmp_pair);
+    return np;
+}
+
+/* ---------------------------------------------------------------- integrator */
+
+/* src/boundary.jl:7-17 wrap_to_box for a diagonal cell:  frac = x/L ; n = floor(frac);
+ * image += Int(n) ; x = L*(frac - n).  (U^-1 x with explicit zeros adds +-0 terms only.) */
+static inline double wrap1(double xc, int32_t *img, double Lc, double invLc)
+{
+    double frac = invLc * xc;
+    double ncross = floor(frac);
+    double fm = frac - ncross;
+    *img += (int32_t)ncross;
+    return Lc * fm;
+}
+
+/* src/integrate.jl:8-21 integrate_half!:  v += (f*dt)/2 ; x += v*dt ; x = wrap(x) */
+void oracle_integrate_half(int dim, int n, double *x, int32_t *img, double *v, const double *f, double dt,
+                           const double *L)
+{
+    double invL[3];
+    for (int c = 0; c < dim; ++c) invL[c] = 1.0 / L[c];
+    for (int i = 0; i < n; ++i)
+        for (int c = 0; c < dim; ++c) {
+            size_t k = (size_t)i * dim + c;
+            v[k] += f[k] * dt / 2.0;
+            x[k] += v[k] * dt;
+            x[k] = wrap1(x[k], &img[k], L[c], invL[c]);
+        }
+}
+
+/* src/integrate.jl:28-38 integrate_second_half! */
+void oracle_integrate_second_half(int dim, int n, double *v, const double *f, double dt)
+{
+    size_t tot = (size_t)n * dim;
+    for (size_t k = 0; k < tot; ++k) v[k] += f[k] * dt / 2.0;
+}
+
+/* src/thermostat.jl:50-60 compute_kinetic (sequential sum, i ascending, sum(abs2,v_i) inner) */
+double oracle_kinetic(int dim, int n, const double *v)
+{
+    double ke = 0.0;
+    for (int i = 0; i < n; ++i) {
+        double s = 0.0;
+        for (int c = 0; c < dim; ++c) s += v[(size_t)i * dim + c] * v[(size_t)i * dim + c];
+        ke += s;
+    }
+    return ke / 2.0;
+}
+
+/* src/thermostat.jl:62-67 */
+double oracle_temperature(int dim, int n, const double *v, double nf)
+{
+    return 2.0 * oracle_kinetic(dim, n, v) / nf;
+}
+
+/* src/thermostat.jl:20-48 bussi! with the two random draws injected (r1 = randn drawn first,
+ * r2 = sum_noises(nf-1)); returns the scale that was applied. */
+double oracle_bussi(int dim, int n, double *v, double ktemp, double nf, double dt, double tau, double r1, double r2)
+{
+    double dt_ratio = dt / tau;
+    double ke = oracle_kinetic(dim, n, v);
+    double tc = 2.0 * ke / nf;
+    double term_1 = exp(-dt_ratio);
+    double c2 = (1.0 - term_1) * ktemp / (tc * nf);
+    double term_2 = c2 * (r2 + r1 * r1);
+    double term_3 = 2.0 * r1 * sqrt(term_1 * c2);
+    double scale = sqrt(term_1 + term_2 + term_3);
+    size_t tot = (size_t)n * dim;
+    for (size_t k = 0; k < tot; ++k) v[k] = v[k] * scale;
+    return scale;
+}
+
+/* src/simulation.jl:88-136 -- the step loop.  ensemble: 0 = NVE, 1 = NVT (Bussi).
+ * ktemp[s], r1[s], r2[s] are per-step inputs for NVT (ktemp[s] = ens.ktemp(s+1), the
+ * 1-based step the reference passes, src/simulation.jl:108).  thermo (if non-NULL) receives
+ * 4 doubles per output step (step % frequency == 0):  step, U_raw, T, W_raw  -- raw sums,
+ * the per-particle / LRC / pressure formulas are applied by the caller so both sides of a
+ * comparison use one implementation of them.  use_cells: 0 brute force, 1 linked cells. */
+int oracle_run(int dim, int n, double *x, int32_t *img, double *v, double *f, const double *diam, const double *L,
+               double cutoff, const oracle_pot *pot, double dt, int ensemble, double tau, double nf,
+               const double *ktemp, const double *r1, const double *r2, int nsteps, int frequency, double *thermo,
+               int use_cells, int nthreads, double *last_uwk)
+{
+    double U = 0.0, W = 0.0, T = 0.0;
+    int nout = 0;
+    for (int step = 0; step < nsteps; ++step) {
+        oracle_integrate_half(dim, n, x, img, v, f, dt, L);
+        if (use_cells)
+            oracle_forces_cells(dim, n, x, L, cutoff, pot, diam, f, &U, &W, nthreads);
+        else
+            oracle_forces_brute(dim, n, x, L, cutoff, pot, diam, f, &U, &W, NULL, 0);
+        oracle_integrate_second_half(dim, n, v, f, dt);
+        if (ensemble == 1) oracle_bussi(dim, n, v, ktemp[step], nf, dt, tau, r1[step], r2[step]);
+        T = oracle_temperature(dim, n, v, nf);
+        if (thermo && frequency > 0 && step % frequency == 0) {
+            thermo[4 * nout + 0] = (double)step;
+            thermo[4 * nout + 1] = U;
+            thermo[4 * nout + 2] = T;
+            thermo[4 * nout + 3] = W;
+            ++nout;
+        }
+    }
+    if (last_uwk) {
+        last_uwk[0] = U;
+        last_uwk[1] = W;
+        last_uwk[2] = 0.5 * T * nf;
+    }
+    return nout;
+}
+
+int oracle_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

@@ -1,0 +1,183 @@
+"""ctypes binding of oracle/libmdoracle.so (the CPU restatement of the reference path).
+
+TEST INFRASTRUCTURE ONLY -- importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg; the product package never imports this module.  Parity is UNPINNED (see
+md_oracle.c header): the reference has no fixtures and cannot run in the build image.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libmdoracle.so")
+
+POT_LJ, POT_PSEUDOHS, POT_POLYDISPERSE = 0, 1, 2
+
+
+class OraclePot(C.Structure):
+    _fields_ = [("kind", C.c_int), ("p", C.c_double * 8)]
+
+
+def make_pot(kind, params):
+    p = OraclePot()
+    p.kind = int(kind)
+    for i, v in enumerate(params):
+        p.p[i] = float(v)
+    return p
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        L = C.CDLL(_SO)
+        dp = C.POINTER(C.c_double)
+        ip = C.POINTER(C.c_int32)
+        pp = C.POINTER(OraclePot)
+        L.oracle_evaluate.argtypes = [pp, C.c_double, C.c_double, C.c_double, dp, dp]
+        L.oracle_evaluate.restype = None
+        L.oracle_ener_lrc.argtypes = [C.c_double] * 3
+        L.oracle_ener_lrc.restype = C.c_double
+        L.oracle_pressure_lrc.argtypes = [C.c_double] * 3
+        L.oracle_pressure_lrc.restype = C.c_double
+        L.oracle_forces_brute.argtypes = [C.c_int, C.c_int, dp, dp, C.c_double, pp, dp, dp, dp, dp, ip, C.c_int64]
+        L.oracle_forces_brute.restype = C.c_int64
+        L.oracle_forces_cells.argtypes = [C.c_int, C.c_int, dp, dp, C.c_double, pp, dp, dp, dp, dp, C.c_int]
+        L.oracle_forces_cells.restype = C.c_int64
+        L.oracle_pairs_cells.argtypes = [C.c_int, C.c_int, dp, dp, C.c_double, ip, C.c_int64]
+        L.oracle_pairs_cells.restype = C.c_int64
+        L.oracle_integrate_half.argtypes = [C.c_int, C.c_int, dp, ip, dp, dp, C.c_double, dp]
+        L.oracle_integrate_half.restype = None
+        L.oracle_integrate_second_half.argtypes = [C.c_int, C.c_int, dp, dp, C.c_double]
+        L.oracle_integrate_second_half.restype = None
+        L.oracle_kinetic.argtypes = [C.c_int, C.c_int, dp]
+        L.oracle_kinetic.restype = C.c_double
+        L.oracle_temperature.argtypes = [C.c_int, C.c_int, dp, C.c_double]
+        L.oracle_temperature.restype = C.c_double
+        L.oracle_bussi.argtypes = [C.c_int, C.c_int, dp] + [C.c_double] * 6
+        L.oracle_bussi.restype = C.c_double
+        L.oracle_run.argtypes = [C.c_int, C.c_int, dp, ip, dp, dp, dp, dp, C.c_double, pp, C.c_double, C.c_int,
+                                 C.c_double, C.c_double, dp, dp, dp, C.c_int, C.c_int, dp, C.c_int, C.c_int, dp]
+        L.oracle_run.restype = C.c_int
+        L.oracle_max_threads.argtypes = []
+        L.oracle_max_threads.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _d(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _i(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def evaluate(pot, r, s1, s2):
+    u, f = C.c_double(), C.c_double()
+    lib().oracle_evaluate(C.byref(pot), r, s1, s2, C.byref(u), C.byref(f))
+    return u.value, f.value
+
+
+def forces_brute(x, box, cutoff, pot, diam, want_pairs=False):
+    """x: (N,d) array (row i = particle i; same memory as Julia's d x N column-major)."""
+    x = _f64(x)
+    n, d = x.shape
+    box = _f64(box)
+    diam = _f64(diam)
+    f = np.zeros_like(x)
+    u, w = C.c_double(), C.c_double()
+    pairs = None
+    cap = 0
+    if want_pairs:
+        cap = lib().oracle_pairs_cells(d, n, _d(x), _d(box), cutoff, None, 0)
+        pairs = np.zeros((max(cap, 1), 2), dtype=np.int32)
+    npairs = lib().oracle_forces_brute(d, n, _d(x), _d(box), cutoff, C.byref(pot), _d(diam), _d(f), C.byref(u),
+                                       C.byref(w), _i(pairs) if want_pairs else None, cap)
+    if want_pairs:
+        return f, u.value, w.value, pairs[:npairs]
+    return f, u.value, w.value, npairs
+
+
+def forces_cells(x, box, cutoff, pot, diam, nthreads=0):
+    x = _f64(x)
+    n, d = x.shape
+    box = _f64(box)
+    diam = _f64(diam)
+    f = np.zeros_like(x)
+    u, w = C.c_double(), C.c_double()
+    npairs = lib().oracle_forces_cells(d, n, _d(x), _d(box), cutoff, C.byref(pot), _d(diam), _d(f), C.byref(u),
+                                       C.byref(w), nthreads)
+    return f, u.value, w.value, npairs
+
+
+def pairs_cells(x, box, cutoff):
+    x = _f64(x)
+    n, d = x.shape
+    box = _f64(box)
+    cnt = lib().oracle_pairs_cells(d, n, _d(x), _d(box), cutoff, None, 0)
+    pairs = np.zeros((max(cnt, 1), 2), dtype=np.int32)
+    cnt2 = lib().oracle_pairs_cells(d, n, _d(x), _d(box), cutoff, _i(pairs), cnt)
+    assert cnt2 == cnt
+    return pairs[:cnt]
+
+
+def run(x, img, v, f, diam, box, cutoff, pot, dt, nsteps, ensemble=0, tau=0.1, ktemp=None, r1=None, r2=None,
+        frequency=0, use_cells=True, nthreads=0):
+    """Runs the reference step loop in place on copies; returns dict of final state + thermo."""
+    x = _f64(x).copy()
+    v = _f64(v).copy()
+    f = _f64(f).copy()
+    img = np.ascontiguousarray(img, dtype=np.int32).copy()
+    n, d = x.shape
+    box = _f64(box)
+    diam = _f64(diam)
+    nf = d * (n - 1.0)
+    kt = _f64(ktemp if ktemp is not None else np.zeros(max(nsteps, 1)))
+    a1 = _f64(r1 if r1 is not None else np.zeros(max(nsteps, 1)))
+    a2 = _f64(r2 if r2 is not None else np.zeros(max(nsteps, 1)))
+    nout_max = (nsteps // frequency + 2) if frequency > 0 else 1
+    thermo = np.zeros((nout_max, 4))
+    last = np.zeros(3)
+    nout = lib().oracle_run(d, n, _d(x), _i(img), _d(v), _d(f), _d(diam), _d(box), cutoff, C.byref(pot), dt,
+                            ensemble, tau, nf, _d(kt), _d(a1), _d(a2), nsteps, frequency,
+                            _d(thermo) if frequency > 0 else None, 1 if use_cells else 0, nthreads, _d(last))
+    return dict(x=x, img=img, v=v, f=f, thermo=thermo[:nout], U=last[0], W=last[1], K=last[2])
+
+
+def integrate_half(x, img, v, f, dt, box):
+    n, d = x.shape
+    lib().oracle_integrate_half(d, n, _d(x), _i(img), _d(v), _d(f), dt, _d(_f64(box)))
+
+
+def integrate_second_half(v, f, dt):
+    n, d = v.shape
+    lib().oracle_integrate_second_half(d, n, _d(v), _d(f), dt)
+
+
+def kinetic(v):
+    n, d = v.shape
+    return lib().oracle_kinetic(d, n, _d(_f64(v)))
+
+
+def bussi(v, ktemp, nf, dt, tau, r1, r2):
+    n, d = v.shape
+    return lib().oracle_bussi(d, n, _d(v), ktemp, nf, dt, tau, r1, r2)
+
+
+def max_threads():
+    return lib().oracle_max_threads()
