@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py -- particle-steps/s of the device-resident MD step loop on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one full velocity-Verlet step (first half-kick + drift, ghost refresh, pair
+forces, second half-kick, thermostat) of every particle.  Workload at N=1: BASELINE.json
+configs[2] -- 1,048,576 monodisperse Lennard-Jones particles, rho = 0.897, r_cut = list
+cutoff = 2.5, dt = 0.001, NVT (Bussi stochastic velocity rescaling, tau = 0.1,
+kT = 1.4737; BASELINE.json calls it "Langevin damping=0.1"), fp64, synthetic
+jittered-lattice start.  Inputs are resident in HBM before the
+timed region starts.
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md for the field meanings).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+STEP_BYTES = {"nve": 332.0, "nvt": 380.0}   # algorithmic bytes per particle-step
+# the fused force kernel reads x (24 B) and v (24 B) and writes f (24 B) and v (24 B) per owned
+# particle (uniform diameter; +8 B sigma otherwise): DESIGN.md "kernels"
+FORCE_KERNEL_BYTES = 96.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--n", type=int, default=1048576, help="particles per GPU")
+    ap.add_argument("--ensemble", choices=["nvt", "nve"], default="nvt")
+    ap.add_argument("--skin", type=float, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=8)
+    ap.add_argument("--equil", type=int, default=200, help="untimed equilibration steps before warmup")
+    return ap.parse_args()
+
+
+def make_inputs(n, seed_shift=0):
+    from moleculardynamics.jl_amd import lattice_positions, initialize_velocities
+    rho, dim, kT = 0.897, 3, 1.4737
+    L = (n / rho) ** (1.0 / 3.0)
+    box = np.full(3, L)
+    x = lattice_positions(n, box, dim, np.random.default_rng(12345 + seed_shift))
+    v = initialize_velocities(kT, np.random.default_rng(67890 + seed_shift), n, dim)
+    return dict(n=n, dim=dim, box=box, x=x, v=v, f=np.zeros_like(x), img=np.zeros((n, dim), dtype=np.int32),
+                diam=np.ones(n), kT=kT, rho=rho)
+
+
+def cpu_baseline(inp, steps, dt):
+    """The oracle's linked-cell path (OpenMP, privatised force buffers) timed on the host cores,
+    on a bounded sample: the same 1M-particle workload for `steps` steps (NVE loop; the Bussi
+    rescale is O(N) noise next to the pair loop)."""
+    from oracle import oracle as orc
+    pot = orc.make_pot(orc.POT_LJ, [1.0, 1.0, 2.5])
+    nthreads = orc.max_threads()
+    w = make_inputs(4096)  # spin up the OpenMP pool / page in the library, untimed
+    orc.forces_cells(w["x"], w["box"], 2.5, pot, w["diam"], nthreads=nthreads)
+    t0 = time.perf_counter()
+    orc.run(inp["x"], inp["img"], inp["v"], inp["f"], inp["diam"], inp["box"], 2.5, pot, dt, steps, use_cells=True,
+            nthreads=nthreads)
+    el = time.perf_counter() - t0
+    return dict(value=inp["n"] * steps / el, unit="particle-steps/s", cores=nthreads, kind="port",
+                sample=f"{steps} steps of the same N={inp['n']} workload (NVE loop), oracle linked cells + OpenMP, "
+                       f"{el:.1f} s wall")
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+
+    from moleculardynamics.jl_amd import MDDevice, _lib
+    from moleculardynamics.jl_amd.thermostat import draw_bussi
+
+    dt, tau = 0.001, 0.1
+    inp = make_inputs(a.n, seed_shift=rank)
+    nf = 3.0 * (a.n - 1.0)
+    nvt = a.ensemble == "nvt"
+    dev = MDDevice(3, a.n, inp["box"], 2.5, device_id=local_rank)
+    dev.set_potential(_lib.MD_POT_LJ, [1.0, 1.0, 2.5])
+    if a.skin is not None:
+        dev.set_skin(a.skin)
+    dev.upload(inp["x"], inp["v"], inp["f"], inp["img"], inp["diam"])
+    rng = np.random.default_rng(4242 + rank)
+
+    def run(nsteps, thermo=False):
+        if nsteps <= 0:
+            return None
+        if nvt:
+            kt = np.full(nsteps, inp["kT"])
+            r1, r2 = draw_bussi(nf, rng, nsteps)
+            return dev.run(nsteps, dt, _lib.MD_NVT, tau, nf, kt, r1, r2, thermo=thermo)
+        return dev.run(nsteps, dt, _lib.MD_NVE, thermo=thermo)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run(a.equil)           # melt the lattice so the timed region sees a liquid, untimed
+    run(a.warmup)
+    st0 = dev.stats()
+    dev.profile(True)
+    barrier()
+    t0 = time.perf_counter()
+    uwk = run(a.steps, thermo=True)
+    barrier()
+    el = time.perf_counter() - t0
+    st1 = dev.stats()
+    dev.profile(False)
+
+    if dist is not None:
+        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+
+    total_particles = a.n * world
+    value = total_particles * a.steps / el
+    launches = max(1, st1["force_launches"])
+    kern_ms = st1["force_ms"] / launches
+    achieved = (FORCE_KERNEL_BYTES * a.n) / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+    step_bytes = STEP_BYTES[a.ensemble]
+    out = {
+        "metric": "particle-steps/sec + achieved HBM GB/s, 1M LJ particles rho=0.897, 1/2/4/8 GPUs",
+        "value": value,
+        "unit": "particle-steps/s",
+        "n_gpus": world,
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "ms_per_step": el * 1e3 / a.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"BASELINE configs[2]: N={a.n} monodisperse LJ 3D rho=0.897 r_cut=2.5 dt=0.001 "
+                        f"{'NVT Bussi tau=0.1 kT=1.4737' if nvt else 'NVE'}, per GPU",
+            "particles_per_gpu": a.n,
+            "parallelism": "1 GPU" if world == 1 else f"{world} independent replicas (no data-path collective yet)",
+            "skin": a.skin if a.skin is not None else 0.3,
+            "rebuilds_in_timed_region": st1["rebuilds"] - st0["rebuilds"],
+            "avg_list_candidates": st1["avg_neighbors"],
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": "k_force (pair forces + second half-kick + KE partials)",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": None,
+            "kernel_ms": kern_ms,
+            "kernel_launches": launches,
+            "bytes_per_launch": FORCE_KERNEL_BYTES * a.n,
+        },
+        "step_roofline": {
+            "algorithmic_bytes_per_particle_step": step_bytes,
+            "achieved_GBps": value / world * step_bytes / 1e9,
+            "frac_of_8TBps": value / world * step_bytes / 1e9 / HBM_PEAK_GBPS,
+        },
+        "thermo_last_step": {"U_per_particle": uwk[0] / a.n, "T": 2.0 * uwk[2] / nf, "W": uwk[1]},
+    }
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(inp, a.cpu_steps, dt)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    dev.close()
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

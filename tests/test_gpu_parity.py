@@ -122,16 +122,15 @@ def test_nvt_bussi_injected_noise(oracle):
 
 def test_wrap_and_images(oracle):
     """Fast particles cross the periodic faces: wrapped positions and image counters must match."""
-    s = lj_system(1024, kT=400.0)
+    s = lj_system(1024, kT=8.0)
     pot = oracle.make_pot(oracle.POT_LJ, LJ)
-    ref = oracle.run(s["x"], s["img"], s["v"], s["f"], s["diam"], s["box"], 2.5, pot, 0.002, 40, use_cells=False)
-    assert np.abs(ref["img"]).max() >= 1
+    ref = oracle.run(s["x"], s["img"], s["v"], s["f"], s["diam"], s["box"], 2.5, pot, 0.001, 150, use_cells=False)
+    assert np.abs(ref["img"]).max() >= 1 and np.count_nonzero(ref["img"]) >= 10
     with _dev(s, 2.5) as d:
-        d.run(40, 0.002)
+        d.run(150, 0.001)
         x, v, f, img = d.download()
     assert np.array_equal(img, ref["img"])
-    # chaotic growth at kT=400 over 40 steps is still tiny
-    assert np.abs(x - ref["x"]).max() <= 1e-8
+    assert np.abs(x - ref["x"]).max() <= 1e-9
 
 
 def test_pseudohs(oracle):
