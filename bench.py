@@ -57,13 +57,30 @@ def make_inputs(n, seed_shift=0):
                 diam=np.ones(n), kT=kT, rho=rho)
 
 
+def host_cores(omp_max):
+    """Threads the CPU baseline may use: the cores this process is actually allowed (affinity and
+    cgroup quota), capped at 16 -- a one-GPU box's CPU share."""
+    n = omp_max
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(p))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
 def cpu_baseline(inp, steps, dt):
     """The oracle's linked-cell path (OpenMP, privatised force buffers) timed on the host cores,
     on a bounded sample: the same 1M-particle workload for `steps` steps (NVE loop; the Bussi
     rescale is O(N) noise next to the pair loop)."""
     from oracle import oracle as orc
     pot = orc.make_pot(orc.POT_LJ, [1.0, 1.0, 2.5])
-    nthreads = orc.max_threads()
+    nthreads = host_cores(orc.max_threads())
     w = make_inputs(4096)  # spin up the OpenMP pool / page in the library, untimed
     orc.forces_cells(w["x"], w["box"], 2.5, pot, w["diam"], nthreads=nthreads)
     t0 = time.perf_counter()

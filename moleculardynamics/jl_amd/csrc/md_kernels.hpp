@@ -25,10 +25,10 @@
 enum { POT_LJ = 0, POT_PSEUDOHS = 1, POT_POLYDISPERSE = 2, POT_CUSTOM = 100 };
 
 struct DevState {
-    double *x[3];  // cap+1 entries: owned [0,n), ghosts [n,next), sentinel at cap
+    double4 *pos;  // cap+1 records (x, y, z, diameter): owned [0,n), ghosts [n,next), sentinel at cap.
+                   // One 32-byte record per particle so a neighbour gather touches one cache line.
     double *v[3];  // n
     double *f[3];  // n
-    double *sigma; // cap+1
     int32_t *img[3];
     int32_t *id;   // cap+1: original particle index (ghost: its owner's)
     double *x0[3]; // n: positions at the last list build
@@ -220,26 +220,41 @@ __device__ __forceinline__ void pair_eval(double d2, double si, double sj, const
 // arithmetic, applied lazily: only when a particle is actually outside the cell) and count
 // the periodic ghost copies each particle needs.
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double pos_get(const double4 &p, int c) { return c == 0 ? p.x : (c == 1 ? p.y : p.z); }
+__device__ __forceinline__ void pos_set(double4 &p, int c, double v)
+{
+    if (c == 0)
+        p.x = v;
+    else if (c == 1)
+        p.y = v;
+    else
+        p.z = v;
+}
+
 template <int D>
 __global__ void __launch_bounds__(MD_BLOCK) k_wrap_count(int n, DevState s, BoxGrid g, int32_t *__restrict__ nimg)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int cnt = 1;
+    double4 p = s.pos[i];
+    bool moved = false;
 #pragma unroll
     for (int c = 0; c < D; ++c) {
-        double xc = s.x[c][i];
+        double xc = pos_get(p, c);
         if (xc < 0.0 || xc >= g.L[c]) {
             double frac = g.invL[c] * xc;
             double nn = floor(frac);
             double fm = frac - nn;
             s.img[c][i] += (int32_t)nn;
             xc = g.L[c] * fm;
-            s.x[c][i] = xc;
+            pos_set(p, c, xc);
+            moved = true;
         }
         int cc = cell_coord<D>(xc, c, g);
         if (cc == 0 || cc == g.nc[c] - 1) cnt *= 2;
     }
+    if (moved) s.pos[i] = p;
     nimg[i] = cnt - 1;
 }
 
@@ -253,9 +268,10 @@ __global__ void __launch_bounds__(MD_BLOCK)
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int cc[3] = {0, 0, 0}, b[3] = {0, 0, 0};
+    double4 p = s.pos[i];
 #pragma unroll
     for (int c = 0; c < D; ++c) {
-        cc[c] = cell_coord<D>(s.x[c][i], c, g);
+        cc[c] = cell_coord<D>(pos_get(p, c), c, g);
         b[c] = (cc[c] == 0) ? 1 : ((cc[c] == g.nc[c] - 1) ? 2 : 0);
     }
     uint64_t idv = (uint64_t)(uint32_t)s.id[i];
@@ -287,6 +303,19 @@ __global__ void __launch_bounds__(MD_BLOCK)
     }
 }
 
+__device__ __forceinline__ double4 shifted(double4 p, uint32_t code, const BoxGrid &g)
+{
+    // x_ghost = x_owner + s*L, s in {-1,0,+1} per component (2 bits each: 1 = +L, 2 = -L)
+    uint32_t sx = code & 3u, sy = (code >> 2) & 3u, sz = (code >> 4) & 3u;
+    if (sx == 1u) p.x = p.x + g.L[0];
+    if (sx == 2u) p.x = p.x - g.L[0];
+    if (sy == 1u) p.y = p.y + g.L[1];
+    if (sy == 2u) p.y = p.y - g.L[1];
+    if (sz == 1u) p.z = p.z + g.L[2];
+    if (sz == 2u) p.z = p.z - g.L[2];
+    return p;
+}
+
 // stage 3 (after the radix sort): move every array into the new order, create the ghost
 // copies' translated coordinates, find the cell ranges.
 template <int D>
@@ -301,15 +330,8 @@ __global__ void __launch_bounds__(MD_BLOCK)
     uint32_t val = vals[k];
     int src = (int)(val & MD_VAL_SRC_MASK);
     uint32_t code = val >> MD_VAL_SRC_BITS;
-#pragma unroll
-    for (int c = 0; c < D; ++c) {
-        double xc = so.x[c][src];
-        uint32_t sh = (code >> (2 * c)) & 3u;
-        if (sh == 1u) xc = xc + g.L[c];
-        if (sh == 2u) xc = xc - g.L[c];
-        sn.x[c][k] = xc;
-    }
-    sn.sigma[k] = so.sigma[src];
+    double4 p = shifted(so.pos[src], code, g);
+    sn.pos[k] = p;
     sn.id[k] = so.id[src];
     if (k < n) {
 #pragma unroll
@@ -317,7 +339,7 @@ __global__ void __launch_bounds__(MD_BLOCK)
             sn.v[c][k] = so.v[c][src];
             sn.f[c][k] = so.f[c][src];
             sn.img[c][k] = so.img[c][src];
-            sn.x0[c][k] = sn.x[c][k];
+            sn.x0[c][k] = pos_get(p, c);
         }
         newslot[src] = k;
     } else {
@@ -353,16 +375,7 @@ __global__ void __launch_bounds__(MD_BLOCK)
     int gi = blockIdx.x * blockDim.x + threadIdx.x;
     if (gi >= nghost) return;
     if (sc->first_viol <= step) return;
-    int o = gowner[gi];
-    uint32_t code = gcode[gi];
-#pragma unroll
-    for (int c = 0; c < D; ++c) {
-        double xc = s.x[c][o];
-        uint32_t sh = (code >> (2 * c)) & 3u;
-        if (sh == 1u) xc = xc + g.L[c];
-        if (sh == 2u) xc = xc - g.L[c];
-        s.x[c][n + gi] = xc;
-    }
+    s.pos[n + gi] = shifted(s.pos[gowner[gi]], gcode[gi], g);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -382,15 +395,13 @@ __global__ void __launch_bounds__(MD_BLOCK)
     int lane = threadIdx.x & 63;
     int tile = k >> 6;
     uint32_t *row = nlist + ((size_t)tile * maxn) * 64 + lane;
+    const double4 *__restrict__ P = s.pos;
     int cnt = 0;
     if (active) {
-        double xi[3] = {0, 0, 0};
+        double4 pi = P[k];
         int ec[3] = {0, 0, 0};
 #pragma unroll
-        for (int c = 0; c < D; ++c) {
-            xi[c] = s.x[c][k];
-            ec[c] = cell_coord<D>(xi[c], c, g) + 1;
-        }
+        for (int c = 0; c < D; ++c) ec[c] = cell_coord<D>(pos_get(pi, c), c, g) + 1;
         int z0 = (D == 3) ? -1 : 0, z1 = (D == 3) ? 1 : 0;
         for (int dz = z0; dz <= z1; ++dz)
             for (int dy = -1; dy <= 1; ++dy)
@@ -399,12 +410,13 @@ __global__ void __launch_bounds__(MD_BLOCK)
                     int cell = ext_linear(e, g);
                     int js = cell_start[cell], je = cell_end[cell];
                     for (int j = js; j < je; ++j) {
-                        double ddx = s.x[0][j] - xi[0];
-                        double ddy = s.x[1][j] - xi[1];
+                        double4 pj = P[j];
+                        double ddx = pj.x - pi.x;
+                        double ddy = pj.y - pi.y;
                         double d2 = ddx * ddx;
                         d2 = __builtin_fma(ddy, ddy, d2);
                         if constexpr (D == 3) {
-                            double ddz = s.x[2][j] - xi[2];
+                            double ddz = pj.z - pi.z;
                             d2 = __builtin_fma(ddz, ddz, d2);
                         }
                         if (d2 <= rl2 && j != k) {
@@ -427,9 +439,9 @@ __global__ void __launch_bounds__(MD_BLOCK)
 }
 
 // ------------------------------------------------------------------------------------------
-// The force kernel.  One lane per owned particle; neighbour coordinates are gathered by
-// index (ghost copies carry translated coordinates, so there is no minimum-image arithmetic
-// in the loop).  Full-neighbour form: every pair is evaluated from both ends, no scatter, no
+// The force kernel.  One lane per owned particle; neighbour records are gathered by index
+// (ghost copies carry translated coordinates, so there is no minimum-image arithmetic in the
+// loop).  Full-neighbour form: every pair is evaluated from both ends, no scatter, no
 // atomics, bitwise reproducible.  Epilogue: F store, optional second half-kick
 // v += (F*dt)/2 (src/integrate.jl:33) and per-block partials of sum v^2, U, W.
 // ------------------------------------------------------------------------------------------
@@ -449,41 +461,30 @@ __global__ void __launch_bounds__(MD_BLOCK)
     int tile = kk >> 6;
     const uint32_t *row = nlist + ((size_t)tile * maxn) * 64 + lane;
     int m = nmax_tile[tile];
-    double xi = s.x[0][kk], yi = s.x[1][kk], zi = 0.0;
-    if constexpr (D == 3) zi = s.x[2][kk];
-    double si = 0.0;
-    if constexpr (!UNIFORM) si = s.sigma[kk];
+    const double4 *__restrict__ P = s.pos;
+    double4 pi = P[kk];
     double fx = 0.0, fy = 0.0, fz = 0.0, us = 0.0, ws = 0.0;
-    const double *__restrict__ X = s.x[0];
-    const double *__restrict__ Y = s.x[1];
-    const double *__restrict__ Z = s.x[2];
-    const double *__restrict__ S = s.sigma;
     for (int r = 0; r < m; r += 4) {
         uint32_t j[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) j[q] = row[(size_t)(r + q) * 64];
-        double xj[4], yj[4], zj[4], sj[4];
+        double4 pj[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pj[q] = P[j[q]];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            xj[q] = X[j[q]];
-            yj[q] = Y[j[q]];
-            if constexpr (D == 3) zj[q] = Z[j[q]];
-            if constexpr (!UNIFORM) sj[q] = S[j[q]];
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            double dx = xj[q] - xi;
-            double dy = yj[q] - yi;
+            double dx = pj[q].x - pi.x;
+            double dy = pj[q].y - pi.y;
             double d2 = dx * dx;
             d2 = __builtin_fma(dy, dy, d2);
             double dz = 0.0;
             if constexpr (D == 3) {
-                dz = zj[q] - zi;
+                dz = pj[q].z - pi.z;
                 d2 = __builtin_fma(dz, dz, d2);
             }
             bool hit = d2 < pp.c2;
             double u = 0.0, fpr;
-            pair_eval<POT, UNIFORM, WANT_UW>(d2, si, UNIFORM ? 0.0 : sj[q], pp, u, fpr);
+            pair_eval<POT, UNIFORM, WANT_UW>(d2, pi.w, pj[q].w, pp, u, fpr);
             fpr = hit ? fpr : 0.0;
             // F_i += f * (x_i - x_j)/r = -fpr * d
             fx = __builtin_fma(-fpr, dx, fx);
@@ -545,22 +546,23 @@ __global__ void __launch_bounds__(MD_BLOCK) k_kickdrift(int n, DevState s, doubl
     if (k < n) {
         double scale = 1.0;
         if constexpr (SCALE) scale = sc->scale;
+        double4 p = s.pos[k];
 #pragma unroll
         for (int c = 0; c < D; ++c) {
             double vc = s.v[c][k];
             if constexpr (SCALE) vc = vc * scale;
             vc = vc + (s.f[c][k] * dt) / 2.0;
             s.v[c][k] = vc;
-            double xc = s.x[c][k] + vc * dt;
-            s.x[c][k] = xc;
+            double xc = pos_get(p, c) + vc * dt;
+            pos_set(p, c, xc);
             double d = xc - s.x0[c][k];
             disp2 = __builtin_fma(d, d, disp2);
         }
+        s.pos[k] = p;
     }
-    double wm = wave_max_d(disp2);
-    if ((threadIdx.x & 63) == 0) {
-        if (wm > thr2) atomicMin(&sc->first_viol, step);
-        atomicMax(&sc->max_disp2_bits, (unsigned long long)__double_as_longlong(wm));
+    // one atomic per violating wave only (a same-address atomic from every wave serialises)
+    if (__any(disp2 > thr2)) {
+        if ((threadIdx.x & 63) == 0) atomicMin(&sc->first_viol, step);
     }
 }
 
@@ -648,16 +650,18 @@ __global__ void __launch_bounds__(MD_BLOCK)
     const uint32_t *row = nlist + ((size_t)tile * maxn) * 64 + lane;
     int cnt = nneigh[k];
     int a = s.id[k];
+    double4 pk = s.pos[k];
     for (int r = 0; r < cnt; ++r) {
         uint32_t j = row[(size_t)r * 64];
         int b = s.id[j];
         if (a >= b) continue;
-        double dx = s.x[0][j] - s.x[0][k];
-        double dy = s.x[1][j] - s.x[1][k];
+        double4 pj = s.pos[j];
+        double dx = pj.x - pk.x;
+        double dy = pj.y - pk.y;
         double d2 = dx * dx;
         d2 = __builtin_fma(dy, dy, d2);
         if constexpr (D == 3) {
-            double dz = s.x[2][j] - s.x[2][k];
+            double dz = pj.z - pk.z;
             d2 = __builtin_fma(dz, dz, d2);
         }
         if (d2 <= c2_inclusive) {
@@ -679,9 +683,10 @@ __global__ void __launch_bounds__(MD_BLOCK)
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     size_t o = (size_t)s.id[k] * D;
+    double4 p = s.pos[k];
 #pragma unroll
     for (int c = 0; c < D; ++c) {
-        double xc = s.x[c][k];
+        double xc = pos_get(p, c);
         int32_t im = s.img[c][k];
         if (xc < 0.0 || xc >= g.L[c]) {
             double frac = g.invL[c] * xc;
@@ -705,12 +710,14 @@ __global__ void __launch_bounds__(MD_BLOCK)
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     size_t o = (size_t)s.id[k] * D;
+    double4 p = s.pos[k];
 #pragma unroll
     for (int c = 0; c < D; ++c) {
-        if (xi) s.x[c][k] = xi[o + c];
+        if (xi) pos_set(p, c, xi[o + c]);
         if (vi) s.v[c][k] = vi[o + c];
         if (fi) s.f[c][k] = fi[o + c];
         if (ii) s.img[c][k] = ii[o + c];
     }
-    if (di) s.sigma[k] = di[s.id[k]];
+    if (di) p.w = di[s.id[k]];
+    if (xi || di) s.pos[k] = p;
 }

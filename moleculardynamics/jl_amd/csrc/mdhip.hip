@@ -63,7 +63,8 @@ struct DBuf {
 };
 
 struct StateBufs {
-    DBuf<double> x[3], v[3], f[3], sigma, x0[3];
+    DBuf<double4> pos;
+    DBuf<double> v[3], f[3], x0[3];
     DBuf<int32_t> img[3], id;
 };
 
@@ -134,14 +135,13 @@ struct md_ctx {
     {
         DevState s{};
         StateBufs &b = sb[which];
+        s.pos = b.pos.p;
         for (int c = 0; c < 3; ++c) {
-            s.x[c] = b.x[c].p;
             s.v[c] = b.v[c].p;
             s.f[c] = b.f[c].p;
             s.img[c] = b.img[c].p;
             s.x0[c] = b.x0[c].p;
         }
-        s.sigma = b.sigma.p;
         s.id = b.id.p;
         return s;
     }
@@ -156,8 +156,8 @@ __global__ void k_init_state(int n, int64_t cap, DevState s, int dim)
     int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k > cap) return;
     bool sent = (k == cap);
-    for (int c = 0; c < dim; ++c) s.x[c][k] = sent ? MD_SENTINEL_POS : 0.0;
-    s.sigma[k] = 1.0;
+    double sp = sent ? MD_SENTINEL_POS : 0.0;
+    s.pos[k] = make_double4(sp, sp, dim == 3 ? sp : 0.0, 1.0);
     s.id[k] = sent ? -1 : (k < n ? (int32_t)k : 0);
     if (k < n)
         for (int c = 0; c < dim; ++c) {
@@ -178,14 +178,13 @@ __global__ void k_reset_flags(Scalars *sc)
 void alloc_state(md_ctx *c, int which, int64_t cap)
 {
     StateBufs &b = c->sb[which];
+    b.pos.alloc(cap + 1);
     for (int d = 0; d < c->dim; ++d) {
-        b.x[d].alloc(cap + 1);
         b.v[d].alloc(c->n);
         b.f[d].alloc(c->n);
         b.img[d].alloc(c->n);
         b.x0[d].alloc(c->n);
     }
-    b.sigma.alloc(cap + 1);
     b.id.alloc(cap + 1);
 }
 
@@ -257,34 +256,23 @@ void ensure_capacity(md_ctx *c, int64_t need_next)
     if (need_next <= c->cap) return;
     int64_t newcap = need_next + need_next / 8 + 1024;
     // grow both state buffers, preserving the current one's owned entries
-    int dim = c->dim;
     for (int w = 0; w < 2; ++w) {
         StateBufs &b = c->sb[w];
-        for (int d = 0; d < dim; ++d) {
-            DBuf<double> nx;
-            nx.alloc(newcap + 1);
-            if (w == c->cur) HIPCHK(hipMemcpyAsync(nx.p, b.x[d].p, sizeof(double) * c->n, hipMemcpyDeviceToDevice, c->stream));
-            double sent = MD_SENTINEL_POS;
-            HIPCHK(hipMemcpyAsync(nx.p + newcap, &sent, sizeof(double), hipMemcpyHostToDevice, c->stream));
-            HIPCHK(hipStreamSynchronize(c->stream));
-            std::swap(b.x[d].p, nx.p);
-            std::swap(b.x[d].n, nx.n);
-        }
-        DBuf<double> ns;
-        ns.alloc(newcap + 1);
+        DBuf<double4> np;
+        np.alloc(newcap + 1);
         DBuf<int32_t> ni;
         ni.alloc(newcap + 1);
         if (w == c->cur) {
-            HIPCHK(hipMemcpyAsync(ns.p, b.sigma.p, sizeof(double) * c->n, hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(hipMemcpyAsync(np.p, b.pos.p, sizeof(double4) * c->n, hipMemcpyDeviceToDevice, c->stream));
             HIPCHK(hipMemcpyAsync(ni.p, b.id.p, sizeof(int32_t) * c->n, hipMemcpyDeviceToDevice, c->stream));
         }
-        double one = 1.0;
+        double4 sent = make_double4(MD_SENTINEL_POS, MD_SENTINEL_POS, c->dim == 3 ? MD_SENTINEL_POS : 0.0, 1.0);
         int32_t m1 = -1;
-        HIPCHK(hipMemcpyAsync(ns.p + newcap, &one, sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(np.p + newcap, &sent, sizeof(double4), hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipMemcpyAsync(ni.p + newcap, &m1, sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
-        std::swap(b.sigma.p, ns.p);
-        std::swap(b.sigma.n, ns.n);
+        std::swap(b.pos.p, np.p);
+        std::swap(b.pos.n, np.n);
         std::swap(b.id.p, ni.p);
         std::swap(b.id.n, ni.n);
     }

@@ -147,7 +147,7 @@ def test_pseudohs(oracle):
 
 def test_polydisperse_2d(oracle):
     s = poly_system()
-    cutoff = 1.25 * 1.62
+    cutoff = 1.25 * 1.2
     pot = oracle.make_pot(oracle.POT_POLYDISPERSE, [1.25, 0.2])
     f_ref, u_ref, w_ref, pairs_ref = oracle.forces_brute(s["x"], s["box"], cutoff, pot, s["diam"], want_pairs=True)
     with _dev(s, cutoff, kind=2, params=[1.25, 0.2]) as d:
@@ -161,6 +161,7 @@ def test_polydisperse_2d(oracle):
         assert abs(w - w_ref) <= 1e-12 * abs(w_ref)
         ref = oracle.run(s["x"], s["img"], s["v"], s["f"], s["diam"], s["box"], cutoff, pot, 0.005, 20,
                          use_cells=False)
+        d.upload(s["x"], s["v"], s["f"], s["img"], s["diam"])
         d.run(20, 0.005)
         x, v, _, img = d.download()
     assert np.abs(x - ref["x"]).max() <= 1e-10
