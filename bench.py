@@ -179,6 +179,8 @@ def main():
             "skin": a.skin if a.skin is not None else 0.3,
             "rebuilds_in_timed_region": st1["rebuilds"] - st0["rebuilds"],
             "avg_list_candidates": st1["avg_neighbors"],
+            "tiled_force_kernel": bool(st1["tiled"]),
+            "max_tile_halo": st1["max_halo"],
         },
         "roofline": {
             "bound": "hbm",

@@ -115,6 +115,8 @@ typedef struct {
     double avg_neighbors;   /* mean list length of the last build (candidates/particle) */
     int64_t force_launches; /* force-kernel launches timed since md_profile(ctx,1) */
     double force_ms;        /* their summed duration, HIP events on the handle's stream */
+    int64_t max_halo;       /* largest per-tile halo (LDS-staged neighbours) of the last build */
+    int64_t tiled;          /* 1 if the LDS-tiled force kernel is in use, 0 if the global-gather one */
 } md_stats;
 int md_profile(md_ctx *ctx, int enable);
 int md_get_stats(md_ctx *ctx, md_stats *out);

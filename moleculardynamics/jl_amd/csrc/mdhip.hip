@@ -103,7 +103,14 @@ struct md_ctx {
     int ncell_ext = 0;
 
     DBuf<int32_t> nimg, img_off, newslot, gsrc, gowner, cell_start, cell_end, nneigh, nmax_tile;
-    DBuf<uint32_t> gcode, vals_in, vals_out, nlist;
+    DBuf<uint32_t> gcode, vals_in, vals_out, nlist, halo;
+    DBuf<uint16_t> nlist16;
+    DBuf<int32_t> halo_count;
+    int hcap = 4096;       // halo slots per tile in global memory
+    int hstride = 0;       // LDS plane stride (doubles) of the last build
+    size_t tile_lds = 0;   // dynamic LDS bytes of the tiled force kernel
+    bool use_tiles = false;
+    bool allow_tiles = true;
     DBuf<uint64_t> keys_in, keys_out;
     DBuf<char> sort_tmp, scan_tmp;
     int maxn = 0;
@@ -173,6 +180,8 @@ __global__ void k_reset_flags(Scalars *sc)
     sc->first_viol = MD_NO_VIOLATION;
     sc->max_disp2_bits = 0ull;
     sc->overflow = 0;
+    sc->hmax = 0;
+    sc->halo_overflow = 0;
 }
 
 void alloc_state(md_ctx *c, int which, int64_t cap)
@@ -226,7 +235,16 @@ void configure_grid(md_ctx *c)
             g.ncx[d] = 1;
             g.inv_cell[d] = 0.0;
         }
-        ncell *= g.ncx[d];
+    }
+    // brick-major cell numbering: 12-cell bricks (2x2x3 in 3-D, 4x3 in 2-D)
+    if (c->dim == 3) {
+        g.bd[0] = 2; g.bd[1] = 2; g.bd[2] = 3;
+    } else {
+        g.bd[0] = 4; g.bd[1] = 3; g.bd[2] = 1;
+    }
+    for (int d = 0; d < 3; ++d) {
+        g.nb[d] = (g.ncx[d] + g.bd[d] - 1) / g.bd[d];
+        ncell *= (int64_t)g.nb[d] * g.bd[d];
     }
     if (ncell > (1ll << 30)) throw HipError("cell grid too large");
     c->ncell_ext = (int)ncell;
@@ -343,6 +361,30 @@ void rebuild_t(md_ctx *c)
         if (attempt == 7) throw HipError("neighbour rows keep overflowing");
         c->maxn = ((c->maxn * 3 / 2) + 3) & ~3;
         c->nlist.alloc((size_t)c->ntiles * c->maxn * 64);
+        c->nlist16.alloc((size_t)c->ntiles * c->maxn * 64);
+    }
+    c->use_tiles = false;
+    if (c->allow_tiles) {
+        static bool attr_set = false;
+        size_t lds = (size_t)MD_HT * 4 + (size_t)MD_HT * 2 + (MD_TILE + 1) * 4;
+        if (!attr_set) {
+            HIPCHK(hipFuncSetAttribute((const void *)k_tile_localize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
+        k_tile_localize<<<c->nblk, MD_TILE, lds, st>>>(c->nlist.p, c->nlist16.p, c->maxn, c->nmax_tile.p,
+                                                       (uint32_t)c->cap, c->halo.p, c->hcap, c->halo_count.p,
+                                                       c->scal.p);
+        Scalars h;
+        HIPCHK(hipMemcpyAsync(&h, c->scal.p, sizeof(Scalars), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        int planes = c->uniform_sigma ? 3 : 4;
+        int stride = (h.hmax + 1 + 1) & ~1;
+        size_t bytes = (size_t)stride * 8 * planes;
+        if (!h.halo_overflow && bytes <= 150 * 1024) {
+            c->use_tiles = true;
+            c->hstride = stride;
+            c->tile_lds = bytes;
+        }
     }
     c->list_valid = true;
     c->steps_since_build = 0;
@@ -400,8 +442,33 @@ void launch_force_tpu(md_ctx *c, bool want_uw, bool kick, double dt, int step)
     k_force<D, POT, UNIFORM, UW, KK><<<nb, MD_BLOCK, 0, c->stream>>>(n, s, c->pp, c->nlist.p, c->maxn,              \
                                                                      c->nmax_tile.p, dt, c->partials.p, nb,         \
                                                                      c->scal.p, step)
+#define LT(UW, KK)                                                                                                  \
+    do {                                                                                                            \
+        static size_t attr_bytes = 0;                                                                               \
+        auto kfn = k_force_tile<D, POT, UNIFORM, UW, KK>;                                                           \
+        if (c->tile_lds > attr_bytes) {                                                                             \
+            HIPCHK(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,               \
+                                       (int)(160 * 1024 - 256)));                                                   \
+            attr_bytes = 160 * 1024;                                                                                \
+        }                                                                                                           \
+        kfn<<<nb, MD_TILE, c->tile_lds, c->stream>>>(n, s, c->pp, c->nlist16.p, c->maxn, c->nmax_tile.p, c->halo.p, \
+                                                     c->hcap, c->halo_count.p, c->hstride, dt, c->partials.p, nb,   \
+                                                     c->scal.p, step);                                              \
+    } while (0)
     prof_begin(c);
-    if (want_uw) {
+    if (c->use_tiles) {
+        if (want_uw) {
+            if (kick)
+                LT(true, true);
+            else
+                LT(true, false);
+        } else {
+            if (kick)
+                LT(false, true);
+            else
+                LT(false, false);
+        }
+    } else if (want_uw) {
         if (kick)
             LF(true, true);
         else
@@ -414,6 +481,7 @@ void launch_force_tpu(md_ctx *c, bool want_uw, bool kick, double dt, int step)
     }
     prof_end(c);
 #undef LF
+#undef LT
 }
 
 template <int D>
@@ -552,6 +620,7 @@ int md_create(int dim, int64_t n_particles, const double *box, double list_cutof
         ctx->n = n_particles;
         for (int c = 0; c < dim; ++c) ctx->L[c] = box[c * dim + c];
         ctx->rc = list_cutoff;
+        if (const char *e = getenv("MDHIP_NO_TILES")) ctx->allow_tiles = !(e[0] == '1');
         // default potential: LennardJones() -- src/potentials.jl:52-64
         ctx->pot_kind = POT_LJ;
         ctx->pp.p[0] = 1.0;
@@ -589,6 +658,9 @@ int md_create(int dim, int64_t n_particles, const double *box, double list_cutof
         int maxn = (int)(dens * vol * 1.35) + 24;
         ctx->maxn = (maxn + 3) & ~3;
         ctx->nlist.alloc((size_t)ctx->ntiles * ctx->maxn * 64);
+        ctx->nlist16.alloc((size_t)ctx->ntiles * ctx->maxn * 64);
+        ctx->halo.alloc((size_t)ctx->nblk * ctx->hcap);
+        ctx->halo_count.alloc(ctx->nblk);
         ctx->partials.alloc((size_t)3 * ctx->nblk);
         HIPCHK(hipMemsetAsync(ctx->partials.p, 0, sizeof(double) * 3 * ctx->nblk, ctx->stream));
         ctx->scal.alloc(1);
@@ -670,6 +742,7 @@ int md_set_skin(md_ctx *ctx, double skin)
         if (maxn > ctx->maxn) {
             ctx->maxn = maxn;
             ctx->nlist.alloc((size_t)ctx->ntiles * ctx->maxn * 64);
+            ctx->nlist16.alloc((size_t)ctx->ntiles * ctx->maxn * 64);
         }
     }
     ctx->target_interval = 8;
@@ -951,6 +1024,8 @@ int md_get_stats(md_ctx *ctx, md_stats *out)
         for (int32_t v : h) sum += v;
         out->avg_neighbors = sum / (double)ctx->n;
     }
+    out->max_halo = ctx->use_tiles ? ctx->hstride : 0;
+    out->tiled = ctx->use_tiles ? 1 : 0;
     out->force_launches = ctx->prof_launch_acc;
     out->force_ms = ctx->prof_ms_acc;
     API_END
