@@ -1,0 +1,353 @@
+// md_build_tile.hpp -- fused per-tile neighbour build (included from md_kernels.hpp).
+//
+// One workgroup per tile (256 consecutive owned slots) does the linked-cell sweep out of LDS
+// and emits the 16-bit rows and the tile's halo list directly; it replaces k_build_list +
+// k_tile_localize on the fast path.
+//   1. the tile's non-empty owned cells -> their 27-neighbourhoods -> sorted unique cell list
+//      (bitonic sort in LDS: a deterministic layout);
+//   2. every particle of those cells staged in LDS as fp32 coordinates relative to the tile's
+//      first particle;
+//   3. sweep 0: two threads per particle (cells 0-13 / 14-26 of the fixed 27-cell order) test
+//      d^2 <= rl^2 (1 + margin) against the LDS image, mark what the tile keeps, count;
+//   4. the marked particles are compacted into the tile's halo;
+//   5. sweep 1 repeats the tests and writes the rows with the compact indices, padded to the
+//      wave maximum with the halo's sentinel slot.
+// The list is a superset structure: the force kernel re-tests every entry against the
+// potential's cutoff in fp64 each step, so building it in fp32 with a safety margin changes
+// no result (an extra candidate contributes an exact zero).  fp32 halves both the VALU time
+// and the LDS footprint of the sweep, which at one workgroup per CU was latency-bound.
+#pragma once
+
+#define MD_BT_THREADS 512
+#define MD_SCAP 3584  // staged particles per tile (LDS capacity)
+#define MD_NCMAX 1024 // neighbour-cell candidates per tile (before dedupe)
+#define MD_NEMAX 36   // non-empty owned cells per tile (36 * 27 <= MD_NCMAX)
+#define MD_INF_CELL 0x7fffffff
+#define MD_SWB 8
+
+// exclusive scan of one int per thread over the block; returns the prefix, *total gets the
+// block sum.  lds: >= 16 ints.  Contains barriers: call from uniform control flow.
+__device__ __forceinline__ int block_excl_scan(int v, int *lds, int *total)
+{
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        int t = __shfl_up(inc, off);
+        if (lane >= off) inc += t;
+    }
+    __syncthreads();
+    if (lane == 63) lds[w] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+    int nw = (blockDim.x + 63) >> 6;
+    for (int i = 0; i < nw; ++i) {
+        int t = lds[i];
+        if (i < w) base += t;
+        tot += t;
+    }
+    *total = tot;
+    return base + inc - v;
+}
+
+// One sweep of a thread's share [n0,n1) of the 27 (9) neighbour cells over the LDS image.
+// PASS 0 marks the staged particles the tile keeps; PASS 1 writes row entries starting at
+// `cnt0`.  Candidates are taken eight at a time with every LDS read of the batch issued
+// before the first use.
+template <int D, int PASS>
+__device__ __forceinline__ int tile_sweep(float xi, float yi, float zi, const int *ec, const BoxGrid &g, float rl2f,
+                                          int self_q, int n0, int n1, const float *px, const float *py,
+                                          const float *pz, const int *ucell, const int *coff, int nu,
+                                          unsigned char *ref, const uint16_t *newidx, uint16_t *row, int maxn,
+                                          int cnt0)
+{
+    int cnt = cnt0;
+    for (int nbi = n0; nbi < n1; ++nbi) {
+        int dx = nbi % 3 - 1, dy = (nbi / 3) % 3 - 1, dz = (D == 3) ? nbi / 9 - 1 : 0;
+        int e[3] = {ec[0] + dx, ec[1] + dy, (D == 3) ? ec[2] + dz : 0};
+        int cell = ext_linear(e, g);
+        int lo = 0, hi = nu;
+        while (hi - lo > 1) {
+            int mid = (lo + hi) >> 1;
+            if (ucell[mid] <= cell)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        if (nu == 0 || ucell[lo] != cell) continue; // empty cell
+        int qs = coff[lo], qe = coff[lo + 1];
+        for (int q0 = qs; q0 < qe; q0 += MD_SWB) {
+            float xq[MD_SWB], yq[MD_SWB], zq[MD_SWB];
+            uint32_t nq[MD_SWB];
+#pragma unroll
+            for (int b = 0; b < MD_SWB; ++b) {
+                int q = min(q0 + b, qe - 1);
+                xq[b] = px[q];
+                yq[b] = py[q];
+                if constexpr (D == 3) zq[b] = pz[q];
+                if constexpr (PASS == 1) nq[b] = newidx[q];
+            }
+#pragma unroll
+            for (int b = 0; b < MD_SWB; ++b) {
+                int q = q0 + b;
+                float ddx = xq[b] - xi;
+                float ddy = yq[b] - yi;
+                float d2 = ddx * ddx;
+                d2 = __builtin_fmaf(ddy, ddy, d2);
+                if constexpr (D == 3) {
+                    float ddz = zq[b] - zi;
+                    d2 = __builtin_fmaf(ddz, ddz, d2);
+                }
+                if (q < qe && d2 <= rl2f && q != self_q) {
+                    if constexpr (PASS == 0) {
+                        ref[q] = 1;
+                    } else {
+                        if (cnt < maxn) row[(size_t)cnt * 64] = (uint16_t)nq[b];
+                    }
+                    ++cnt;
+                }
+            }
+        }
+    }
+    return cnt;
+}
+
+template <int D>
+__global__ void __launch_bounds__(MD_BT_THREADS)
+    k_build_tile(int n, DevState s, BoxGrid g, float rl2f, const int32_t *__restrict__ cell_start,
+                 const int32_t *__restrict__ cell_end, uint16_t *__restrict__ nlist16, int maxn,
+                 int32_t *__restrict__ nneigh, int32_t *__restrict__ nmax_tile, uint32_t *__restrict__ halo, int hcap,
+                 int32_t *__restrict__ halo_count, Scalars *sc, long long *__restrict__ stamps)
+{
+#define MD_STAMP(i)                                                                                   \
+    do {                                                                                              \
+        if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 10 + (i)] = (long long)clock64(); \
+    } while (0)
+    MD_STAMP(0);
+    __shared__ float px[MD_SCAP], py[MD_SCAP], pz[MD_SCAP];
+    __shared__ uint16_t newidx[MD_SCAP];
+    __shared__ unsigned char ref[MD_SCAP];
+    __shared__ int ccell[MD_NCMAX], ucell[MD_NCMAX], coff[MD_NCMAX + 2];
+    __shared__ int cntA[MD_TILE];
+    __shared__ int sh_misc[4];
+    __shared__ int sh_scan[16];
+    __shared__ int sh_ne[MD_NEMAX];
+
+    const int tile = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int half = tid / MD_TILE;         // 0: cells [0,nA)   1: cells [nA, NNB)
+    const int pt = tid - half * MD_TILE;    // particle of the tile this thread works for
+    const int k = tile * MD_TILE + pt;
+    const bool active = k < n;
+    const double4 *__restrict__ P = s.pos;
+    const int NNB = (D == 3) ? 27 : 9;
+    const int nA = (NNB + 1) / 2;
+
+    const double4 org = P[tile * MD_TILE]; // tile-local frame: keeps fp32 coordinates small
+    double4 pd = P[active ? k : n - 1];
+    const float xi = (float)(pd.x - org.x), yi = (float)(pd.y - org.y), zi = (D == 3) ? (float)(pd.z - org.z) : 0.f;
+    int ec[3] = {0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < D; ++c) ec[c] = cell_coord<D>(pos_get(pd, c), c, g) + 1;
+    const int mycell = ext_linear(ec, g);
+    if (tid == 0) sh_misc[0] = mycell; // first particle's cell
+    const int last_active = min(n - 1, tile * MD_TILE + MD_TILE - 1) - tile * MD_TILE;
+    if (tid == last_active) sh_misc[1] = mycell;
+    if (tid == 0) sh_misc[2] = 0;
+    for (int i = tid; i < MD_SCAP; i += MD_BT_THREADS) ref[i] = 0;
+    __syncthreads();
+    const int c_first = sh_misc[0], c_last = sh_misc[1];
+    const int R = c_last - c_first + 1; // index slots spanned (includes unused brick slots)
+    // 1a. the non-empty owned cells of the range (order irrelevant: sorted below)
+    for (int ci = tid; ci < R; ci += MD_BT_THREADS) {
+        int cell = c_first + ci;
+        if (cell_end[cell] > cell_start[cell]) {
+            int pos = atomicAdd(&sh_misc[2], 1);
+            if (pos < MD_NEMAX) sh_ne[pos] = cell;
+        }
+    }
+    __syncthreads();
+    const int nne = sh_misc[2];
+    bool bad = (nne > MD_NEMAX) || (nne * NNB > MD_NCMAX);
+    int M = 64; // sort size: next power of two >= nne*NNB
+    while (M < nne * NNB && M < MD_NCMAX) M <<= 1;
+    // 1b. their neighbour cells
+    for (int t = tid; t < M; t += MD_BT_THREADS) {
+        int v = MD_INF_CELL;
+        if (!bad && t < nne * NNB) {
+            int ci = t / NNB, nb = t - ci * NNB;
+            int e[3];
+            ext_decode(sh_ne[ci], g, e);
+            int dx = nb % 3 - 1, dy = (nb / 3) % 3 - 1, dz = (D == 3) ? nb / 9 - 1 : 0;
+            int e2[3] = {e[0] + dx, e[1] + dy, e[2] + dz};
+            int nc = ext_linear(e2, g);
+            if (cell_end[nc] > cell_start[nc]) v = nc;
+        }
+        ccell[t] = v;
+    }
+    __syncthreads();
+    MD_STAMP(1);
+    // bitonic sort (ascending; the INF padding ends up last)
+    for (int kk = 2; kk <= M; kk <<= 1)
+        for (int j = kk >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < M; i += MD_BT_THREADS) {
+                int ixj = i ^ j;
+                if (ixj > i) {
+                    bool asc = (i & kk) == 0;
+                    int a = ccell[i], b = ccell[ixj];
+                    if ((a > b) == asc) {
+                        ccell[i] = b;
+                        ccell[ixj] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    MD_STAMP(2);
+    // unique cells + staging offsets: each thread owns per_c consecutive sorted entries
+    const int per_c = (M + MD_BT_THREADS - 1) / MD_BT_THREADS;
+    int my_nu = 0, my_cnt = 0;
+    for (int q = 0; q < per_c; ++q) {
+        int i = tid * per_c + q;
+        if (i < M) {
+            int c = ccell[i];
+            if (c != MD_INF_CELL && (i == 0 || ccell[i - 1] != c)) {
+                ++my_nu;
+                my_cnt += cell_end[c] - cell_start[c];
+            }
+        }
+    }
+    int tot_nu, tot_S;
+    int base_nu = block_excl_scan(my_nu, sh_scan, &tot_nu);
+    int base_S = block_excl_scan(my_cnt, sh_scan, &tot_S);
+    for (int q = 0; q < per_c; ++q) {
+        int i = tid * per_c + q;
+        if (i < M) {
+            int c = ccell[i];
+            if (c != MD_INF_CELL && (i == 0 || ccell[i - 1] != c)) {
+                ucell[base_nu] = c;
+                coff[base_nu] = base_S;
+                ++base_nu;
+                base_S += cell_end[c] - cell_start[c];
+            }
+        }
+    }
+    if (tid == 0) coff[tot_nu] = tot_S;
+    __syncthreads();
+    const int nu = tot_nu;
+    const int S = tot_S;
+    if (tid == 0) {
+        atomicMax(&sc->dbg_rmax, nne);
+        atomicMax(&sc->dbg_smax, S);
+    }
+    if (S > MD_SCAP) bad = true;
+    if (bad) {
+        // this tile does not fit the fast path: the host falls back to the two-kernel build
+        if (tid == 0) atomicOr(&sc->halo_overflow, 2);
+        return;
+    }
+    MD_STAMP(3);
+    // 2. stage (fp32, relative to the tile origin)
+    for (int i = tid; i < S; i += MD_BT_THREADS) {
+        int lo = 0, hi = nu; // last u with coff[u] <= i
+        while (hi - lo > 1) {
+            int mid = (lo + hi) >> 1;
+            if (coff[mid] <= i)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        int slot = cell_start[ucell[lo]] + (i - coff[lo]);
+        double4 p = P[slot];
+        px[i] = (float)(p.x - org.x);
+        py[i] = (float)(p.y - org.y);
+        if constexpr (D == 3) pz[i] = (float)(p.z - org.z);
+    }
+    // this particle's own index in the staged image (its cell is its own neighbour, so it is staged)
+    int self_q = -1;
+    if (active) {
+        int lo = 0, hi = nu;
+        while (hi - lo > 1) {
+            int mid = (lo + hi) >> 1;
+            if (ucell[mid] <= mycell)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        self_q = coff[lo] + (k - cell_start[mycell]);
+    }
+    __syncthreads();
+    MD_STAMP(4);
+    // 3. sweep 0: mark + count
+    const int wt = tile * (MD_TILE / 64) + (pt >> 6);
+    uint16_t *row = nlist16 + ((size_t)wt * maxn) * 64 + lane;
+    const int n0 = half ? nA : 0, n1 = half ? NNB : nA;
+    int cnt = 0;
+    if (active)
+        cnt = tile_sweep<D, 0>(xi, yi, zi, ec, g, rl2f, self_q, n0, n1, px, py, pz, ucell, coff, nu, ref, newidx, row,
+                               maxn, 0);
+    if (half == 0) cntA[pt] = cnt;
+    __syncthreads();
+    MD_STAMP(5);
+    // 4. compact the referenced particles into the halo
+    int H;
+    {
+        const int per = MD_SCAP / MD_BT_THREADS;
+        int c = 0;
+        for (int q = 0; q < per; ++q) c += ref[tid * per + q];
+        int run = block_excl_scan(c, sh_scan, &H);
+        for (int q = 0; q < per; ++q) {
+            int i = tid * per + q;
+            if (ref[i]) {
+                newidx[i] = (uint16_t)run;
+                if (run < hcap) {
+                    int lo = 0, hi = nu;
+                    while (hi - lo > 1) {
+                        int mid = (lo + hi) >> 1;
+                        if (coff[mid] <= i)
+                            lo = mid;
+                        else
+                            hi = mid;
+                    }
+                    halo[(size_t)tile * hcap + run] = (uint32_t)(cell_start[ucell[lo]] + (i - coff[lo]));
+                }
+                ++run;
+            }
+        }
+        if (tid == 0) {
+            halo_count[tile] = H;
+            atomicMax(&sc->hmax, H);
+            if (H > hcap) atomicOr(&sc->halo_overflow, 1);
+        }
+    }
+    __syncthreads();
+    MD_STAMP(6);
+    // 5. sweep 1: write the rows.  The second-half thread appends after the first half's entries.
+    const int cA = cntA[pt];
+    const int start = half ? cA : 0;
+    int endc = start;
+    if (active)
+        endc = tile_sweep<D, 1>(xi, yi, zi, ec, g, rl2f, self_q, n0, n1, px, py, pz, ucell, coff, nu, ref, newidx, row,
+                                maxn, start);
+    __syncthreads();
+    MD_STAMP(7);
+    if (half == 1) cntA[pt] = endc; // total = cA + cB
+    __syncthreads();
+    if (half == 0) {
+        int tot = active ? cntA[pt] : 0;
+        if (active) {
+            nneigh[k] = tot;
+            if (tot > maxn) {
+                atomicOr(&sc->overflow, 1);
+                tot = maxn;
+            }
+        }
+        int m = wave_max_i(tot);
+        m = (m + 3) & ~3;
+        if (m > maxn) m = maxn;
+        for (int t = tot; t < m; ++t) row[(size_t)t * 64] = (uint16_t)H;
+        if (lane == 0) nmax_tile[wt] = m;
+    }
+    MD_STAMP(8);
+#undef MD_STAMP
+}

@@ -41,6 +41,7 @@ struct BoxGrid {
     int ncx[3]; // extended (ghost-padded) cells per dim; 1 for an unused dim
     int bd[3];  // brick dims in cells: cells are numbered brick-major so that consecutive
     int nb[3];  // particles (hence a 256-particle tile) form a compact block, not a stick
+    int n_int_cells; // size of the (padded) interior brick-major range; ghost cells follow
     int id_bits, cell_bits;
 };
 
@@ -59,6 +60,7 @@ struct Scalars {
     unsigned long long pair_count;
     int hmax;          // largest tile halo of the last build
     int halo_overflow; // a tile's halo did not fit its slot table
+    int dbg_rmax, dbg_smax; // fused build: largest cell range / staged set of a tile
 };
 
 // ------------------------------------------------------------------------------------------
@@ -140,13 +142,52 @@ __device__ __forceinline__ int cell_coord(double xc, int c, const BoxGrid &g)
     return cc;
 }
 
+// Cell numbering.  Interior cells (extended coords 1..nc) are grouped into bricks -- a balanced
+// partition of each axis into nb[d] ranges of 2-3 (z: 3-4) cells, so there are no sliver
+// bricks when nc is not a multiple of the brick size -- and numbered brick-major, bricks in
+// boustrophedon order (consecutive bricks are always face neighbours).  Consecutive owned
+// particles, hence a 256-particle tile, then form a compact block.  Each brick owns
+// bd[0]*bd[1]*bd[2] index slots (bd = largest brick size; unused slots stay empty).  The
+// ghost layer gets a separate plain range after the interior one.
+__device__ __forceinline__ int brick_of(int i, int nc, int nb) { return ((i + 1) * nb - 1) / nc; }
+__device__ __forceinline__ int brick_start(int b, int nc, int nb) { return (b * nc) / nb; }
+
 __device__ __forceinline__ int ext_linear(const int *e, const BoxGrid &g)
 {
-    int bx = e[0] / g.bd[0], wx = e[0] - bx * g.bd[0];
-    int by = e[1] / g.bd[1], wy = e[1] - by * g.bd[1];
-    int bz = e[2] / g.bd[2], wz = e[2] - bz * g.bd[2];
-    int brick = (bz * g.nb[1] + by) * g.nb[0] + bx;
-    return brick * (g.bd[0] * g.bd[1] * g.bd[2]) + (wz * g.bd[1] + wy) * g.bd[0] + wx;
+    bool interior = true;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        if (g.ncx[c] > 1 && (e[c] < 1 || e[c] > g.nc[c])) interior = false;
+    if (interior) {
+        int i0 = e[0] - 1, i1 = e[1] - 1, i2 = (g.ncx[2] > 1) ? e[2] - 1 : 0;
+        int bx = brick_of(i0, g.nc[0], g.nb[0]), wx = i0 - brick_start(bx, g.nc[0], g.nb[0]);
+        int by = brick_of(i1, g.nc[1], g.nb[1]), wy = i1 - brick_start(by, g.nc[1], g.nb[1]);
+        int bz = brick_of(i2, g.nc[2], g.nb[2]), wz = i2 - brick_start(bz, g.nc[2], g.nb[2]);
+        int byp = (bz & 1) ? g.nb[1] - 1 - by : by;
+        int r = bz * g.nb[1] + byp;
+        int bxp = (r & 1) ? g.nb[0] - 1 - bx : bx;
+        int brick = r * g.nb[0] + bxp;
+        return brick * (g.bd[0] * g.bd[1] * g.bd[2]) + (wz * g.bd[1] + wy) * g.bd[0] + wx;
+    }
+    return g.n_int_cells + (e[2] * g.ncx[1] + e[1]) * g.ncx[0] + e[0];
+}
+
+// inverse of ext_linear for interior cells (only called for slots that hold a real cell)
+__device__ __forceinline__ void ext_decode(int lin, const BoxGrid &g, int *e)
+{
+    int bv = g.bd[0] * g.bd[1] * g.bd[2];
+    int brick = lin / bv, w = lin - brick * bv;
+    int bxp = brick % g.nb[0];
+    int r = brick / g.nb[0];
+    int bx = (r & 1) ? g.nb[0] - 1 - bxp : bxp;
+    int byp = r % g.nb[1], bz = r / g.nb[1];
+    int by = (bz & 1) ? g.nb[1] - 1 - byp : byp;
+    int wx = w % g.bd[0];
+    int t2 = w / g.bd[0];
+    int wy = t2 % g.bd[1], wz = t2 / g.bd[1];
+    e[0] = brick_start(bx, g.nc[0], g.nb[0]) + wx + 1;
+    e[1] = brick_start(by, g.nc[1], g.nb[1]) + wy + 1;
+    e[2] = (g.ncx[2] > 1) ? brick_start(bz, g.nc[2], g.nb[2]) + wz + 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -627,6 +668,8 @@ __global__ void __launch_bounds__(MD_TILE)
     }
 }
 
+#include "md_build_tile.hpp"
+
 // ------------------------------------------------------------------------------------------
 // The tiled force kernel: same arithmetic and summation order as k_force, neighbour
 // coordinates served from an LDS image of the tile's halo (SoA planes: a random 8-byte read
@@ -854,18 +897,21 @@ __global__ void k_set_scale(Scalars *sc, double v) { sc->scale = v; }
 // ------------------------------------------------------------------------------------------
 template <int D>
 __global__ void __launch_bounds__(MD_BLOCK)
-    k_pairs(int n, DevState s, double c2_inclusive, const uint32_t *__restrict__ nlist, int maxn,
+    k_pairs(int n, DevState s, double c2_inclusive, const uint32_t *__restrict__ nlist,
+            const uint16_t *__restrict__ nlist16, const uint32_t *__restrict__ halo, int hcap, int maxn,
             const int32_t *__restrict__ nneigh, int32_t *__restrict__ out, unsigned long long cap, Scalars *sc)
 {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     int lane = threadIdx.x & 63, tile = k >> 6;
-    const uint32_t *row = nlist + ((size_t)tile * maxn) * 64 + lane;
+    size_t rbase = ((size_t)tile * maxn) * 64 + lane;
+    const uint32_t *hl = halo + (size_t)(k / MD_TILE) * hcap;
     int cnt = nneigh[k];
     int a = s.id[k];
     double4 pk = s.pos[k];
     for (int r = 0; r < cnt; ++r) {
-        uint32_t j = row[(size_t)r * 64];
+        // rows are either 32-bit global slots or 16-bit indices into the tile's halo list
+        uint32_t j = nlist16 ? hl[nlist16[rbase + (size_t)r * 64]] : nlist[rbase + (size_t)r * 64];
         int b = s.id[j];
         if (a >= b) continue;
         double4 pj = s.pos[j];

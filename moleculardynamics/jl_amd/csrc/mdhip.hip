@@ -106,11 +106,14 @@ struct md_ctx {
     DBuf<uint32_t> gcode, vals_in, vals_out, nlist, halo;
     DBuf<uint16_t> nlist16;
     DBuf<int32_t> halo_count;
+    DBuf<long long> dbg_stamps;
     int hcap = 4096;       // halo slots per tile in global memory
     int hstride = 0;       // LDS plane stride (doubles) of the last build
     size_t tile_lds = 0;   // dynamic LDS bytes of the tiled force kernel
     bool use_tiles = false;
     bool allow_tiles = true;
+    bool allow_fused_build = true;
+    bool have_nlist32 = false; // the 32-bit global-index rows exist for the current build
     DBuf<uint64_t> keys_in, keys_out;
     DBuf<char> sort_tmp, scan_tmp;
     int maxn = 0;
@@ -182,6 +185,8 @@ __global__ void k_reset_flags(Scalars *sc)
     sc->overflow = 0;
     sc->hmax = 0;
     sc->halo_overflow = 0;
+    sc->dbg_rmax = 0;
+    sc->dbg_smax = 0;
 }
 
 void alloc_state(md_ctx *c, int which, int64_t cap)
@@ -236,16 +241,20 @@ void configure_grid(md_ctx *c)
             g.inv_cell[d] = 0.0;
         }
     }
-    // brick-major cell numbering: 12-cell bricks (2x2x3 in 3-D, 4x3 in 2-D)
-    if (c->dim == 3) {
-        g.bd[0] = 2; g.bd[1] = 2; g.bd[2] = 3;
-    } else {
-        g.bd[0] = 4; g.bd[1] = 3; g.bd[2] = 1;
+    // brick-major cell numbering: balanced bricks of about 2x2x3 cells (4x3 in 2-D)
+    int target[3] = {2, 2, 3};
+    if (c->dim == 2) {
+        target[0] = 4; target[1] = 3; target[2] = 1;
     }
+    int64_t nint = 1, next_plain = 1;
     for (int d = 0; d < 3; ++d) {
-        g.nb[d] = (g.ncx[d] + g.bd[d] - 1) / g.bd[d];
-        ncell *= (int64_t)g.nb[d] * g.bd[d];
+        g.nb[d] = std::max(1, g.nc[d] / target[d]);
+        g.bd[d] = (g.nc[d] + g.nb[d] - 1) / g.nb[d]; // largest brick along d
+        nint *= (int64_t)g.nb[d] * g.bd[d];
+        next_plain *= g.ncx[d];
     }
+    ncell = nint + next_plain;
+    g.n_int_cells = (int)nint;
     if (ncell > (1ll << 30)) throw HipError("cell grid too large");
     c->ncell_ext = (int)ncell;
     g.id_bits = std::max(1, ceil_log2((uint64_t)c->n));
@@ -350,40 +359,91 @@ void rebuild_t(md_ctx *c)
 
     // neighbour rows
     double rl2 = c->rl * c->rl;
-    for (int attempt = 0; attempt < 8; ++attempt) {
-        k_reset_flags<<<1, 1, 0, st>>>(c->scal.p);
-        k_build_list<D><<<nb, MD_BLOCK, 0, st>>>(n, sn, g, rl2, c->cell_start.p, c->cell_end.p, c->nlist.p, c->maxn,
-                                                 c->nneigh.p, c->nmax_tile.p, (uint32_t)c->cap, c->scal.p);
-        Scalars h;
-        HIPCHK(hipMemcpyAsync(&h, c->scal.p, sizeof(Scalars), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        if (!h.overflow) break;
-        if (attempt == 7) throw HipError("neighbour rows keep overflowing");
-        c->maxn = ((c->maxn * 3 / 2) + 3) & ~3;
-        c->nlist.alloc((size_t)c->ntiles * c->maxn * 64);
-        c->nlist16.alloc((size_t)c->ntiles * c->maxn * 64);
-    }
     c->use_tiles = false;
-    if (c->allow_tiles) {
-        static bool attr_set = false;
-        size_t lds = (size_t)MD_HT * 4 + (size_t)MD_HT * 2 + (MD_TILE + 1) * 4;
-        if (!attr_set) {
-            HIPCHK(hipFuncSetAttribute((const void *)k_tile_localize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            attr_set = true;
-        }
-        k_tile_localize<<<c->nblk, MD_TILE, lds, st>>>(c->nlist.p, c->nlist16.p, c->maxn, c->nmax_tile.p,
-                                                       (uint32_t)c->cap, c->halo.p, c->hcap, c->halo_count.p,
-                                                       c->scal.p);
-        Scalars h;
-        HIPCHK(hipMemcpyAsync(&h, c->scal.p, sizeof(Scalars), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
+    c->have_nlist32 = false;
+    bool tile_ok = false;
+    auto set_tiles = [&](const Scalars &h) {
         int planes = c->uniform_sigma ? 3 : 4;
         int stride = (h.hmax + 1 + 1) & ~1;
         size_t bytes = (size_t)stride * 8 * planes;
-        if (!h.halo_overflow && bytes <= 150 * 1024) {
+        if (!(h.halo_overflow) && bytes <= 150 * 1024) {
             c->use_tiles = true;
             c->hstride = stride;
             c->tile_lds = bytes;
+            if (const char *e = getenv("MDHIP_LDS_PAD")) c->tile_lds += (size_t)atoi(e);
+            return true;
+        }
+        return false;
+    };
+    auto grow_rows = [&]() {
+        c->maxn = ((c->maxn * 3 / 2) + 3) & ~3;
+        c->nlist.alloc((size_t)c->ntiles * c->maxn * 64);
+        c->nlist16.alloc((size_t)c->ntiles * c->maxn * 64);
+    };
+    if (c->allow_tiles && c->allow_fused_build) {
+        // fast path: fused LDS-tiled sweep + halo compaction
+        // fp32 sweep radius with a safety margin over fp32 rounding of tile-relative coordinates
+        float rl2f = (float)(rl2 * (1.0 + 1.0e-4));
+        for (int attempt = 0; attempt < 8; ++attempt) {
+            k_reset_flags<<<1, 1, 0, st>>>(c->scal.p);
+            k_build_tile<D><<<c->nblk, MD_BT_THREADS, 0, st>>>(n, sn, g, rl2f, c->cell_start.p, c->cell_end.p,
+                                                               c->nlist16.p, c->maxn, c->nneigh.p, c->nmax_tile.p,
+                                                               c->halo.p, c->hcap, c->halo_count.p, c->scal.p,
+                                                               c->dbg_stamps.p);
+            if (c->dbg_stamps.p) {
+                std::vector<long long> hs((size_t)c->nblk * 10);
+                HIPCHK(hipMemcpyAsync(hs.data(), c->dbg_stamps.p, hs.size() * 8, hipMemcpyDeviceToHost, st));
+                HIPCHK(hipStreamSynchronize(st));
+                double acc[9] = {0};
+                for (int b = 0; b < c->nblk; ++b)
+                    for (int i = 1; i <= 8; ++i) acc[i] += (double)(hs[(size_t)b * 10 + i] - hs[(size_t)b * 10 + i - 1]);
+                fprintf(stderr, "[mdhip] build_tile phase cycles/block: cand %.0f sort %.0f uniq %.0f stage %.0f sweep0 %.0f compact %.0f sweep1 %.0f tail %.0f\n",
+                        acc[1] / c->nblk, acc[2] / c->nblk, acc[3] / c->nblk, acc[4] / c->nblk, acc[5] / c->nblk,
+                        acc[6] / c->nblk, acc[7] / c->nblk, acc[8] / c->nblk);
+            }
+            Scalars h;
+            HIPCHK(hipMemcpyAsync(&h, c->scal.p, sizeof(Scalars), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            if (getenv("MDHIP_DEBUG"))
+                fprintf(stderr, "[mdhip] fused build: Rmax=%d Smax=%d Hmax=%d halo_overflow=%d row_overflow=%d maxn=%d\n",
+                        h.dbg_rmax, h.dbg_smax, h.hmax, h.halo_overflow, h.overflow, c->maxn);
+            if (h.halo_overflow) break; // some tile does not fit: two-kernel path below
+            if (h.overflow) {
+                grow_rows();
+                continue;
+            }
+            tile_ok = set_tiles(h);
+            break;
+        }
+    }
+    if (!tile_ok) {
+        for (int attempt = 0; attempt < 8; ++attempt) {
+            k_reset_flags<<<1, 1, 0, st>>>(c->scal.p);
+            k_build_list<D><<<nb, MD_BLOCK, 0, st>>>(n, sn, g, rl2, c->cell_start.p, c->cell_end.p, c->nlist.p,
+                                                     c->maxn, c->nneigh.p, c->nmax_tile.p, (uint32_t)c->cap,
+                                                     c->scal.p);
+            Scalars h;
+            HIPCHK(hipMemcpyAsync(&h, c->scal.p, sizeof(Scalars), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            if (!h.overflow) break;
+            if (attempt == 7) throw HipError("neighbour rows keep overflowing");
+            grow_rows();
+        }
+        c->have_nlist32 = true;
+        if (c->allow_tiles) {
+            static bool attr_set2 = false;
+            size_t lds = (size_t)MD_HT * 4 + (size_t)MD_HT * 2 + (MD_TILE + 1) * 4;
+            if (!attr_set2) {
+                HIPCHK(hipFuncSetAttribute((const void *)k_tile_localize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                attr_set2 = true;
+            }
+            k_tile_localize<<<c->nblk, MD_TILE, lds, st>>>(c->nlist.p, c->nlist16.p, c->maxn, c->nmax_tile.p,
+                                                           (uint32_t)c->cap, c->halo.p, c->hcap, c->halo_count.p,
+                                                           c->scal.p);
+            Scalars h;
+            HIPCHK(hipMemcpyAsync(&h, c->scal.p, sizeof(Scalars), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            set_tiles(h);
         }
     }
     c->list_valid = true;
@@ -621,6 +681,7 @@ int md_create(int dim, int64_t n_particles, const double *box, double list_cutof
         for (int c = 0; c < dim; ++c) ctx->L[c] = box[c * dim + c];
         ctx->rc = list_cutoff;
         if (const char *e = getenv("MDHIP_NO_TILES")) ctx->allow_tiles = !(e[0] == '1');
+        if (const char *e = getenv("MDHIP_NO_FUSED_BUILD")) ctx->allow_fused_build = !(e[0] == '1');
         // default potential: LennardJones() -- src/potentials.jl:52-64
         ctx->pot_kind = POT_LJ;
         ctx->pp.p[0] = 1.0;
@@ -661,6 +722,7 @@ int md_create(int dim, int64_t n_particles, const double *box, double list_cutof
         ctx->nlist16.alloc((size_t)ctx->ntiles * ctx->maxn * 64);
         ctx->halo.alloc((size_t)ctx->nblk * ctx->hcap);
         ctx->halo_count.alloc(ctx->nblk);
+        if (getenv("MDHIP_STAMPS")) ctx->dbg_stamps.alloc((size_t)ctx->nblk * 10);
         ctx->partials.alloc((size_t)3 * ctx->nblk);
         HIPCHK(hipMemsetAsync(ctx->partials.p, 0, sizeof(double) * 3 * ctx->nblk, ctx->stream));
         ctx->scal.alloc(1);
@@ -849,12 +911,15 @@ int md_neighbor_pairs(md_ctx *ctx, int32_t *pairs, int64_t cap, int64_t *count)
     HIPCHK(hipMemcpyAsync(&ctx->scal.p->pair_count, &zero, sizeof zero, hipMemcpyHostToDevice, st));
     DevState s = ctx->dev(ctx->cur);
     double c2 = ctx->rc * ctx->rc;
+    const uint16_t *l16 = ctx->have_nlist32 ? nullptr : ctx->nlist16.p;
     if (ctx->dim == 3)
-        k_pairs<3><<<ctx->nblk, MD_BLOCK, 0, st>>>((int)ctx->n, s, c2, ctx->nlist.p, ctx->maxn, ctx->nneigh.p, out.p,
-                                                   (unsigned long long)cap, ctx->scal.p);
+        k_pairs<3><<<ctx->nblk, MD_BLOCK, 0, st>>>((int)ctx->n, s, c2, ctx->nlist.p, l16, ctx->halo.p, ctx->hcap,
+                                                   ctx->maxn, ctx->nneigh.p, out.p, (unsigned long long)cap,
+                                                   ctx->scal.p);
     else
-        k_pairs<2><<<ctx->nblk, MD_BLOCK, 0, st>>>((int)ctx->n, s, c2, ctx->nlist.p, ctx->maxn, ctx->nneigh.p, out.p,
-                                                   (unsigned long long)cap, ctx->scal.p);
+        k_pairs<2><<<ctx->nblk, MD_BLOCK, 0, st>>>((int)ctx->n, s, c2, ctx->nlist.p, l16, ctx->halo.p, ctx->hcap,
+                                                   ctx->maxn, ctx->nneigh.p, out.p, (unsigned long long)cap,
+                                                   ctx->scal.p);
     HIPCHK(hipGetLastError());
     Scalars h = read_scalars(ctx);
     int64_t found = (int64_t)h.pair_count;
