@@ -166,3 +166,145 @@ def test_polydisperse_2d(oracle):
         x, v, _, img = d.download()
     assert np.abs(x - ref["x"]).max() <= 1e-10
     assert np.abs(v - ref["v"]).max() <= 1e-10
+
+
+# ---------------------------------------------------------------- committed golden vectors
+import os  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.mark.parametrize("name,n", [("lj_n512_rc2p5.npz", 512), ("lj_n500_rc1p5.npz", 500)])
+def test_device_vs_golden_lj(name, n):
+    g = np.load(os.path.join(GOLD, name))
+    s = lj_system(n)
+    cutoff = float(g["cutoff"])
+    with _dev(s, cutoff) as d:
+        u, w = d.compute_forces()
+        _, _, f, _ = d.download()
+        pairs = d.neighbor_pairs()
+        assert np.array_equal(pairs, g["pairs"])
+        _check_forces(f, g["forces"])
+        assert abs(u - float(g["U"])) <= 1e-12 * abs(float(g["U"]))
+        assert abs(w - float(g["W"])) <= 1e-12 * abs(float(g["W"]))
+        d.upload(s["x"], s["v"], s["f"], s["img"], s["diam"])
+        U, W, K = d.run(int(g["nsteps"]), float(g["dt"]))
+        x, v, f, img = d.download()
+    assert np.abs(x - g["x_end"]).max() <= 1e-10 and np.abs(v - g["v_end"]).max() <= 1e-10
+    assert np.array_equal(img, g["img_end"])
+    assert abs(K - float(g["K_end"])) <= 1e-12 * float(g["K_end"])
+
+
+def test_device_vs_golden_nvt():
+    from moleculardynamics.jl_amd import _lib
+    g = np.load(os.path.join(GOLD, "lj_n512_nvt.npz"))
+    s = lj_system(512, kT=1.4737)
+    with _dev(s, 2.5) as d:
+        U, W, K = d.run(int(g["nsteps"]), float(g["dt"]), _lib.MD_NVT, 0.1, 3 * 511.0, g["kt"], g["r1"], g["r2"])
+        x, v, _, _ = d.download()
+    assert np.abs(x - g["x_end"]).max() <= 1e-10 and np.abs(v - g["v_end"]).max() <= 1e-10
+    assert abs(K - float(g["K_end"])) <= 1e-11 * float(g["K_end"])
+
+
+# ---------------------------------------------------------------- full-size, size-independent properties
+@pytest.mark.parametrize("n", [262144, 1048576])
+def test_full_size_properties(n):
+    """BASELINE configs[1] / [2] sizes: too big for the O(N^2) oracle, so check what must hold at
+    any size: sum F = 0, the lattice energy, and that every list strategy (fresh cells each step,
+    Verlet rows with a skin, fused fp32 tile build, two-kernel fp64 build, global-gather kernel)
+    yields the same forces -- bit-identical on one cell grid, where they differ only in which
+    rejected candidates they carry."""
+    from moleculardynamics.jl_amd import MDDevice
+    s = lj_system(n)
+    results = []
+    for env, skin in [({}, 0.3), ({}, 0.0), ({"MDHIP_NO_FUSED_BUILD": "1"}, 0.3), ({"MDHIP_NO_TILES": "1"}, 0.3)]:
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            with MDDevice(3, n, s["box"], 2.5) as d:
+                d.set_potential(0, LJ)
+                d.set_skin(skin)
+                d.upload(s["x"], s["v"], s["f"], s["img"], s["diam"])
+                u, w = d.compute_forces()
+                _, _, f, _ = d.download()
+                st = d.stats()
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        results.append((f, u, w, st))
+    f0, u0, w0, st0 = results[0]
+    assert st0["tiled"] == 1
+    assert np.abs(f0.sum(axis=0)).max() <= 1e-9 * np.abs(f0).sum()          # Newton's third law
+    assert -4.6 < u0 / n < -4.1      # jittered simple-cubic start at rho=0.897 (oracle at N=4096: -4.385)
+    # same cell grid (same skin): same candidates order -> bitwise; skin 0 uses a different grid,
+    # hence a different summation order -> round-off level
+    for i, (f, u, w, st) in enumerate(results[1:], start=1):
+        if i == 1:
+            _check_forces(f, f0, 1e-12)
+        else:
+            assert np.array_equal(f, f0), "list strategies on one grid disagree bitwise"
+        assert abs(u - u0) <= 1e-13 * abs(u0) and abs(w - w0) <= 1e-13 * abs(w0)
+    assert results[3][3]["tiled"] == 0
+
+
+def test_nve_momentum_and_energy_262k():
+    """BASELINE configs[1]: N=262144 NVE.  Total momentum stays at round-off, energy drift is at
+    the level the truncated-unshifted potential allows."""
+    from moleculardynamics.jl_amd import MDDevice
+    n = 262144
+    s = lj_system(n)
+    with MDDevice(3, n, s["box"], 2.5) as d:
+        d.set_potential(0, LJ)
+        d.upload(s["x"], s["v"], s["f"], s["img"], s["diam"])
+        U1, W1, K1 = d.run(20, 0.001)
+        U2, W2, K2 = d.run(200, 0.001)
+        _, v, _, _ = d.download()
+        st = d.stats()
+    assert np.abs(v.sum(axis=0)).max() < 1e-7
+    assert abs((U2 + K2) - (U1 + K1)) < 2e-2 * abs(U1 + K1)
+    assert st["rebuilds"] >= 2 and st["steps"] == 220
+
+
+# ---------------------------------------------------------------- the driver, end to end (BASELINE configs[0])
+@pytest.mark.parametrize("potname", ["lj", "pseudohs"])
+def test_run_simulation_readme_example(tmp_path, potname):
+    """README example 1 with the actual signatures: N=1024, packing fraction 0.47
+    (rho = 0.8976), kT = 1.4737, NVT equilibration then NVE -- plumbing, file formats, D7."""
+    import moleculardynamics.jl_amd as md
+    rho = 6 * 0.47 / np.pi
+    pot = md.LennardJones() if potname == "lj" else md.PseudoHS()
+    cutoff = 2.5 if potname == "lj" else 1.5
+    dt = 0.001 if potname == "lj" else 0.0005
+    params = md.Parameters(rho, 1000, dt, pot)
+    path = str(tmp_path / potname)
+    if potname == "lj":
+        state = md.initialize_state(params, path, random_init=True, cutoff=cutoff, rng=np.random.default_rng(7))
+    else:
+        # pseudo hard spheres must not start overlapping (the reference removes overlaps with Packmol):
+        # 1 % jitter on the 1.037-spaced lattice keeps every pair beyond sigma
+        L = (1000 / rho) ** (1.0 / 3.0)
+        x0 = md.lattice_positions(1000, np.full(3, L), 3, np.random.default_rng(7), jitter=0.01)
+        state = md.initialize_state(params, path, cutoff=cutoff, positions=x0, diameters=np.ones(1000), unitcell=L)
+    assert os.path.isfile(os.path.join(path, "init.xyz"))
+    state.velocities = md.initialize_velocities(1.4737, np.random.default_rng(8), params.n_particles, 3)
+    md.run_simulation(state, params, md.NVT(1.4737, 100.0 * dt), 60, 20, path, thermo_name="thermo_nvt.txt")
+    f_after_first = state.system.energy_and_forces.forces.copy()
+    assert np.abs(f_after_first).max() > 0           # forces persist on the state for the next call (D7)
+    md.run_simulation(state, params, md.NVE(), 45, 20, path)
+    lines = open(os.path.join(path, "thermo.txt")).read().splitlines()
+    assert lines[0] == "# Step Energy Temperature Pressure"
+    rows = [ln.split() for ln in lines[1:]]
+    assert [int(r[0]) for r in rows] == [0, 20, 40]   # step % frequency == 0, 0-based
+    assert all(len(r) == 4 and re_float.match(r[1]) for r in rows)
+    T = [float(r[2]) for r in rows]
+    assert all(0.5 < t < 3.0 for t in T)
+    assert os.path.isfile(os.path.join(path, "final.xyz")) and os.path.isfile(os.path.join(path, "trajectory.xyz"))
+    assert state.velocities.shape == (1000, 3) and state.images.dtype == np.int32
+    state.system.device.close()
+
+
+import re  # noqa: E402
+re_float = re.compile(r"^-?\d+\.\d{6}$")

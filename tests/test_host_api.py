@@ -1,0 +1,171 @@
+"""CPU tests of the host layer: the reference's API surface mirrored in Python, and the C-ABI
+library's loadability (no compute without a GPU)."""
+import ctypes
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+
+import moleculardynamics.jl_amd as md
+from moleculardynamics.jl_amd import _lib, io as mdio
+from moleculardynamics.jl_amd.thermostat import sum_noises, draw_bussi, bussi_scale
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = _lib.load()
+    header = open(os.path.join(ROOT, "include", "mdhip.h")).read()
+    declared = set(re.findall(r"\b(md_[a-z_]+)\s*\(", header))
+    declared -= {"md_ctx"}
+    assert declared == set(_lib.EXPORTS), f"header and binding disagree: {declared ^ set(_lib.EXPORTS)}"
+    for name in declared:
+        assert hasattr(lib, name), f"libmdhip.so does not export {name}"
+    assert lib.md_version().decode().startswith("mdhip")
+
+
+def test_no_cpu_fallback():
+    """Without a HIP device the product path must fail loudly, never route to a CPU path."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(md.MdhipError, match="no HIP device"):
+        md.MDDevice(3, 100, 20.0, 2.5)
+
+
+def test_create_argument_errors():
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    box = (ctypes.c_double * 9)(10, 0, 0, 0, 10, 0, 0, 0, 10)
+    assert lib.md_create(4, 100, box, 2.5, -1, ctypes.byref(h)) != 0
+    assert b"dim" in lib.md_last_error(None)
+    assert lib.md_create(3, 1, box, 2.5, -1, ctypes.byref(h)) != 0
+    tri = (ctypes.c_double * 9)(10, 0, 0, 1, 10, 0, 0, 0, 10)
+    assert lib.md_create(3, 100, tri, 2.5, -1, ctypes.byref(h)) != 0
+    assert b"orthorhombic" in lib.md_last_error(None)
+    assert lib.md_create(3, 100, box, -1.0, -1, ctypes.byref(h)) != 0
+    assert lib.md_set_skin(None, 0.3) != 0      # null handle is an error, not a crash
+
+
+def test_potential_known_answers():
+    # SURVEY.md section 4
+    assert md.evaluate(md.LennardJones(), 1.0, 1.0, 1.0) == (0.0, 24.0)
+    assert md.evaluate(md.LennardJones(), 1.5, 1.0, 1.0) == (-0.32033659427857464, -1.1580288310461555)
+    assert md.evaluate(md.LennardJones(), 2.5, 1.0, 1.0) == (0.0, 0.0)
+    lj = md.LennardJones()
+    assert lj.V_cut == pytest.approx(-0.01631689113600001, rel=1e-14)
+    assert lj.F_cut == pytest.approx(-0.038999477452800024, rel=1e-14)
+    assert md.evaluate(md.PseudoHS(), 1.0, 1.0, 1.0) == (1.0, pytest.approx(134.5526623421209))
+    assert md.evaluate(md.PseudoHS(), 1.03, 1.0, 1.0) == (0.0, 0.0)
+    u, f = md.evaluate(md.Polydisperse(), 1.0, 1.0, 1.0)
+    assert u == pytest.approx(0.5958195256295423, rel=1e-14) and f == pytest.approx(10.14226515370967, rel=1e-14)
+    assert md.ener_lrc(2.5, 0.897) == pytest.approx(-0.48028349255352715, rel=1e-14)
+    assert md.pressure_lrc(2.5, 0.897) == pytest.approx(-0.8604505670240141, rel=1e-14)
+    # LRC only when tail_correction is set (src/potentials.jl:136-152)
+    assert md.LennardJones().energy_lrc(1000, 1000 / 0.897) == 0.0
+    ljt = md.LennardJones(tail_correction=True)
+    assert ljt.energy_lrc(1000, 1000 / 0.897) == pytest.approx(-480.28349255352715, rel=1e-13)
+
+
+def test_host_potentials_match_oracle(oracle):
+    rng = np.random.default_rng(1)
+    cases = [(md.LennardJones(), oracle.make_pot(0, [1, 1, 2.5])), (md.PseudoHS(), oracle.make_pot(1, [50.0])),
+             (md.Polydisperse(), oracle.make_pot(2, [1.25, 0.2]))]
+    for pot, opot in cases:
+        for _ in range(200):
+            r, s1, s2 = rng.uniform(0.85, 2.7), rng.uniform(0.7, 1.3), rng.uniform(0.7, 1.3)
+            u, f = md.evaluate(pot, r, s1, s2)
+            uo, fo = oracle.evaluate(opot, r, s1, s2)
+            assert u == pytest.approx(uo, rel=1e-12, abs=1e-13) and f == pytest.approx(fo, rel=1e-12, abs=1e-12)
+
+
+def test_plugin_contract():
+    class Bare(md.Potential):
+        pass
+    with pytest.raises(NotImplementedError, match="evaluate not implemented"):
+        md.evaluate(Bare(), 1.0, 1.0, 1.0)
+    with pytest.raises(NotImplementedError, match="device"):
+        Bare().device_spec()
+    assert Bare().energy_lrc(10, 10.0) == 0.0 and Bare().pressure_lrc(10, 10.0) == 0.0
+
+
+def test_ensembles_and_ramps():
+    nvt = md.NVT(1.5, 0.1)
+    assert nvt.ktemp(1) == 1.5 and nvt.ktemp(10 ** 6) == 1.5 and nvt.tau == 0.1
+    ramp = md.LinearRamp(2.0, 1.0, 11)
+    assert ramp(1) == 2.0 and ramp(11) == 1.0 and ramp(6) == pytest.approx(1.5) and ramp(12) == 1.0 and ramp(0) == 2.0
+    assert md.LinearRamp(2.0, 1.0, 1)(1) == 1.0
+    er = md.ExponentialRamp(2.0, 0.5, 3)
+    assert er(1) == 2.0 and er(2) == pytest.approx(1.0) and er(3) == pytest.approx(0.5) and er(99) == 0.5
+    assert md.NVT(ramp, 0.1).ktemp(6) == pytest.approx(1.5)
+    assert md.initial_temperature_for_velocities(ramp) == 2.0
+    assert md.initial_temperature_for_velocities(1.3) == 1.3
+    p = md.Parameters(0.897, 1000, 0.001, md.LennardJones())
+    assert p.ρ == 0.897 and p.n_particles == 1000
+
+
+def test_initialize_velocities_properties():
+    v = md.initialize_velocities(1.4737, np.random.default_rng(3), 1000, 3)
+    assert v.shape == (1000, 3)
+    assert np.abs(v.sum(axis=0)).max() < 1e-10                       # zero COM
+    assert (v * v).sum() / (3 * 999) == pytest.approx(1.4737, rel=1e-13)   # T == kT w.r.t. nf = d(N-1)
+    v2 = md.initialize_velocities(0.11, np.random.default_rng(3), 1200, 2)
+    assert (v2 * v2).sum() / (2 * 1199) == pytest.approx(0.11, rel=1e-13)
+
+
+def test_lattice_initialiser():
+    L = (4096 / 0.897) ** (1 / 3)
+    x = md.lattice_positions(4096, np.full(3, L), 3, np.random.default_rng(12345))
+    assert x.shape == (4096, 3) and x.min() >= 0 and x.max() < L
+    d = np.linalg.norm(x[1:] - x[:-1], axis=1)
+    assert d.min() > 0.85 * L / 16                                    # no overlaps
+    xp = md.lattice_positions(4096, np.full(3, L), 3, np.random.default_rng(12345), permute_seed=777)
+    assert not np.array_equal(x, xp) and np.allclose(np.sort(x[:, 0]), np.sort(xp[:, 0]))
+
+
+def test_sum_noises_and_bussi_draws():
+    rng = np.random.default_rng(0)
+    assert sum_noises(0, rng) == 0.0
+    xs = np.array([sum_noises(6, rng) for _ in range(20000)])
+    assert xs.mean() == pytest.approx(6.0, rel=0.03) and xs.var() == pytest.approx(12.0, rel=0.08)   # chi^2(6)
+    xo = np.array([sum_noises(5, rng) for _ in range(20000)])
+    assert xo.mean() == pytest.approx(5.0, rel=0.03)
+    r1, r2 = draw_bussi(3 * 999.0, np.random.default_rng(1), 50)
+    assert r1.shape == (50,) and r2.mean() == pytest.approx(3 * 999 - 1, rel=0.02)
+    # <scale^2> -> 1 at kT == T_current (stationarity of the thermostat)
+    nf, kT = 3 * 999.0, 1.2
+    K = 0.5 * nf * kT
+    rng = np.random.default_rng(2)
+    s2 = [bussi_scale(K, kT, nf, 0.001, 0.1, rng.standard_normal(), sum_noises(nf - 1, rng)) ** 2 for _ in range(4000)]
+    assert np.mean(s2) == pytest.approx(1.0, abs=2e-4)
+
+
+def test_xyz_roundtrip_and_lammps_dump(tmp_path):
+    n, d = 50, 3
+    rng = np.random.default_rng(0)
+    x = rng.uniform(0, 7, (n, d))
+    diam = rng.uniform(0.8, 1.2, n)
+    cell = np.diag([7.0, 7.0, 7.0])
+    p = tmp_path / "c.xyz"
+    mdio.write_to_file(str(p), 5, cell, n, x, diam, d, mode="w")
+    cell2, x2, diam2 = mdio.read_file(str(p), dimension=d)
+    assert np.allclose(cell2, cell) and np.allclose(x2, x, atol=1e-6) and np.allclose(diam2, diam, atol=2e-6)
+    lines = open(p).read().splitlines()
+    assert lines[0] == "50" and lines[1].startswith('Lattice="7.0 0.0 0.0 0.0 7.0 0.0 0.0 0.0 7.0"')
+    q = tmp_path / "t.lammpstrj"
+    img = rng.integers(-2, 3, (n, d)).astype(np.int32)
+    mdio.write_to_file_lammps(str(q), 7, cell, n, x, img, diam, d, mode="w")
+    ls = open(q).read().splitlines()
+    assert ls[0] == "ITEM: TIMESTEP" and ls[1] == "7" and ls[3] == "50"
+    assert ls[8] == "ITEM: ATOMS id type radius x y z xu yu zu"
+    first = [float(t) for t in ls[9].split()]
+    assert first[0] == 1 and first[6] == pytest.approx(x[0, 0] + 7.0 * img[0, 0], abs=1e-5)
+
+
+def test_run_simulation_rejects_out_of_scope():
+    st = type("S", (), {})()
+    p = md.Parameters(0.9, 10, 0.001, md.LennardJones())
+    with pytest.raises(NotImplementedError, match="Brownian"):
+        md.run_simulation(st, p, md.Brownian(1.0), 10, 1, "/tmp/x")
