@@ -50,6 +50,7 @@ struct PotParams {
     double c2;      // pair accepted iff d2 < c2 (strict form of d2 <= list_cutoff^2 folded with the potential's own r_cut where it has one)
     double sig2u;   // uniform-diameter fast path: ((s+s)/2)^2
     double sig_u;   // the uniform diameter itself
+    double c48, c24, c4; // 48*eps, 24*eps, 4*eps (LJ)
 };
 
 struct Scalars {
@@ -77,6 +78,30 @@ __device__ __forceinline__ double md_rcp(double a)
     r = __builtin_fma(r, e, r);
     return r;
 }
+
+__device__ __forceinline__ double md_rcp1(double a)
+{
+    // v_rcp_f64 (measured 4.5e-8 relative on gfx950) + ONE Newton step: 2e-15 relative, well
+    // inside the 1e-11 force / 1e-12 energy tolerances stated in the parity tests.
+    double r = __builtin_amdgcn_rcp(a);
+    double e = __builtin_fma(-a, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+
+// Rejected candidates are masked by replacing d^2 with a huge finite number (one dword
+// select): every built-in potential then yields an exact (signed) zero contribution.
+__device__ __forceinline__ double mask_d2(double d2, bool hit)
+{
+    int hi = __double2hiint(d2);
+    int lo = __double2loint(d2);
+    hi = hit ? hi : 0x7fe00000;
+    return __hiloint2double(hi, lo);
+}
+
+// Row entries of tile t live at rows16[wave_tile_base + row_off(r, lane)]: groups of four
+// consecutive entries of one lane are adjacent, so the force kernel fetches four indices with
+// one 8-byte load (512 contiguous bytes per wave).
+__device__ __forceinline__ size_t row_off(int r, int lane) { return ((size_t)(r >> 2) * 64 + lane) * 4 + (r & 3); }
 
 __device__ __forceinline__ double md_ipow(double x, int n)
 {
@@ -203,19 +228,20 @@ template <int POT, bool UNIFORM, bool WANT_U>
 __device__ __forceinline__ void pair_eval(double d2, double si, double sj, const PotParams &pp, double &u, double &fpr)
 {
     if constexpr (POT == POT_LJ) {
-        // src/potentials.jl:66-77 in r^-2 form (no sqrt, one reciprocal)
-        double inv = md_rcp(d2);
-        double s2;
+        // src/potentials.jl:66-77 in r^-2 form (no sqrt, one reciprocal):
+        //   w = sigma^2/r^2 ; f/r = (w^3/r^2) (48 eps w^3 - 24 eps) ; u = 4 eps w^3 (w^3 - 1)
+        double inv = md_rcp1(d2);
+        double w;
         if constexpr (UNIFORM) {
-            s2 = pp.sig2u * inv;
+            w = pp.sig2u * inv;
         } else {
             double sg = (si + sj) * 0.5;
-            s2 = (sg * sg) * inv;
+            w = (sg * sg) * inv;
         }
-        double s6 = s2 * s2 * s2;
-        double e24 = 24.0 * pp.p[0];
-        fpr = (e24 * inv) * (s6 * __builtin_fma(2.0, s6, -1.0));
-        if constexpr (WANT_U) u = (4.0 * pp.p[0]) * (s6 * (s6 - 1.0));
+        double w3 = (w * w) * w;
+        double t = __builtin_fma(pp.c48, w3, -pp.c24);
+        fpr = (w3 * inv) * t;
+        if constexpr (WANT_U) u = pp.c4 * (w3 * (w3 - 1.0));
     } else if constexpr (POT == POT_PSEUDOHS) {
         // src/potentials.jl:11-29
         double r = sqrt(d2);
@@ -532,16 +558,16 @@ __global__ void __launch_bounds__(MD_BLOCK)
                 d2 = __builtin_fma(dz, dz, d2);
             }
             bool hit = d2 < pp.c2;
+            double d2m = mask_d2(d2, hit);
             double u = 0.0, fpr;
-            pair_eval<POT, UNIFORM, WANT_UW>(d2, pi.w, pj[q].w, pp, u, fpr);
-            fpr = hit ? fpr : 0.0;
+            pair_eval<POT, UNIFORM, WANT_UW>(d2m, pi.w, pj[q].w, pp, u, fpr);
             // F_i += f * (x_i - x_j)/r = -fpr * d
             fx = __builtin_fma(-fpr, dx, fx);
             fy = __builtin_fma(-fpr, dy, fy);
             if constexpr (D == 3) fz = __builtin_fma(-fpr, dz, fz);
             if constexpr (WANT_UW) {
-                us += hit ? u : 0.0;
-                ws = __builtin_fma(fpr, d2, ws);
+                us += u;
+                ws = __builtin_fma(fpr, hit ? d2 : 0.0, ws);
             }
         }
     }
@@ -598,7 +624,7 @@ __global__ void __launch_bounds__(MD_BLOCK)
 __global__ void __launch_bounds__(MD_TILE)
     k_tile_localize(const uint32_t *__restrict__ nlist, uint16_t *__restrict__ nlist16, int maxn,
                     const int32_t *__restrict__ nmax_tile, uint32_t sentinel, uint32_t *__restrict__ halo, int hcap,
-                    int32_t *__restrict__ halo_count, Scalars *sc)
+                    int32_t *__restrict__ halo_count, Scalars *sc, int rs)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *keys = (uint32_t *)smem;               // MD_HT
@@ -650,21 +676,21 @@ __global__ void __launch_bounds__(MD_TILE)
     if (tid == 0) {
         halo_count[tile] = H;
         atomicMax(&sc->hmax, H);
-        if (H > hcap || H >= 65535) atomicOr(&sc->halo_overflow, 1);
+        if (H > hcap || (H + 1) * rs > 65535) atomicOr(&sc->halo_overflow, 1);
     }
     __syncthreads();
-    uint16_t *row16 = nlist16 + ((size_t)wt * maxn) * 64 + lane;
+    uint16_t *row16 = nlist16 + ((size_t)wt * maxn) * 64;
     for (int r = 0; r < m; ++r) {
         uint32_t j = row[(size_t)r * 64];
-        uint16_t loc;
+        uint32_t loc;
         if (j == sentinel) {
-            loc = (uint16_t)H; // the tile's own far-away slot
+            loc = (uint32_t)H; // the tile's own far-away slot
         } else {
             uint32_t h = (j * 2654435761u) >> (32 - MD_HT_BITS);
             while (keys[h] != j) h = (h + 1) & (MD_HT - 1);
             loc = vals[h];
         }
-        row16[(size_t)r * 64] = loc;
+        row16[row_off(r, lane)] = (uint16_t)(loc * (uint32_t)rs); // byte offset of the LDS record
     }
 }
 
@@ -672,39 +698,34 @@ __global__ void __launch_bounds__(MD_TILE)
 
 // ------------------------------------------------------------------------------------------
 // The tiled force kernel: same arithmetic and summation order as k_force, neighbour
-// coordinates served from an LDS image of the tile's halo (SoA planes: a random 8-byte read
-// per plane spreads over all 64 banks).  Dynamic LDS: (H+1) * 24 bytes (+8 with diameters).
+// coordinates served from an LDS image of the tile's halo.  The image is an array of records
+// of RS bytes (x, y, z [, diameter]); row entries are the records' byte offsets, so a
+// neighbour costs three ds_read_b64 off one address register and no address arithmetic.
+// A stride of 24 or 32 bytes spreads random 8-byte reads over all 64 banks.
+// Dynamic LDS: (H+1) * RS bytes.
 // ------------------------------------------------------------------------------------------
 template <int D, int POT, bool UNIFORM, bool WANT_UW, bool KICK>
 __global__ void __launch_bounds__(MD_TILE)
     k_force_tile(int n, DevState s, PotParams pp, const uint16_t *__restrict__ nlist16, int maxn,
                  const int32_t *__restrict__ nmax_tile, const uint32_t *__restrict__ halo, int hcap,
-                 const int32_t *__restrict__ halo_count, int hstride, double dt, double *__restrict__ partials,
-                 int nblk_total, const Scalars *__restrict__ sc, int step)
+                 const int32_t *__restrict__ halo_count, double dt, double *__restrict__ partials, int nblk_total,
+                 const Scalars *__restrict__ sc, int step)
 {
+    constexpr int RS = UNIFORM ? 24 : 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ double red[16];
     if (sc->first_viol <= step) return;
-    double *lx = (double *)smem;
-    double *ly = lx + hstride;
-    double *lz = ly + hstride;
-    double *lw = lz + hstride;
     int bid = xcd_remap(blockIdx.x, gridDim.x);
     const double4 *__restrict__ P = s.pos;
     int H = halo_count[bid];
     const uint32_t *hl = halo + (size_t)bid * hcap;
-    for (int h = threadIdx.x; h < H; h += MD_TILE) {
-        double4 p = P[hl[h]];
-        lx[h] = p.x;
-        ly[h] = p.y;
-        if constexpr (D == 3) lz[h] = p.z;
-        if constexpr (!UNIFORM) lw[h] = p.w;
-    }
-    if (threadIdx.x == 0) {
-        lx[H] = MD_SENTINEL_POS;
-        ly[H] = MD_SENTINEL_POS;
-        if constexpr (D == 3) lz[H] = MD_SENTINEL_POS;
-        if constexpr (!UNIFORM) lw[H] = 1.0;
+    for (int h = threadIdx.x; h <= H; h += MD_TILE) {
+        double4 p = (h < H) ? P[hl[h]] : make_double4(MD_SENTINEL_POS, MD_SENTINEL_POS, MD_SENTINEL_POS, 1.0);
+        double *rec = (double *)(smem + (size_t)h * RS);
+        rec[0] = p.x;
+        rec[1] = p.y;
+        rec[2] = (D == 3) ? p.z : 0.0;
+        if constexpr (!UNIFORM) rec[3] = p.w;
     }
     __syncthreads();
     int k = bid * MD_TILE + threadIdx.x;
@@ -712,21 +733,27 @@ __global__ void __launch_bounds__(MD_TILE)
     int kk = active ? k : n - 1;
     int lane = threadIdx.x & 63;
     int wt = bid * (MD_TILE / 64) + (threadIdx.x >> 6);
-    const uint16_t *row = nlist16 + ((size_t)wt * maxn) * 64 + lane;
+    const ushort4 *row4 = (const ushort4 *)(nlist16 + ((size_t)wt * maxn) * 64) + lane;
     int m = nmax_tile[wt];
     double4 pi = P[kk];
     double fx = 0.0, fy = 0.0, fz = 0.0, us = 0.0, ws = 0.0;
+    // the row indices of group g+1 are fetched while group g is computed: issued at the top of
+    // the loop and consumed one iteration later, so their memory latency hides under the
+    // pair arithmetic instead of stalling every iteration (vmcnt(0) right after the load)
+    ushort4 jnext = row4[0];
     for (int r = 0; r < m; r += 4) {
-        int j[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) j[q] = row[(size_t)(r + q) * 64];
+        ushort4 jj = jnext;
+        int rn = (r + 4 < m) ? r + 4 : r;
+        jnext = row4[(size_t)(rn >> 2) * 64];
+        unsigned o[4] = {jj.x, jj.y, jj.z, jj.w};
         double xj[4], yj[4], zj[4], wj[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            xj[q] = lx[j[q]];
-            yj[q] = ly[j[q]];
-            if constexpr (D == 3) zj[q] = lz[j[q]];
-            if constexpr (!UNIFORM) wj[q] = lw[j[q]];
+            const double *rec = (const double *)(smem + o[q]);
+            xj[q] = rec[0];
+            yj[q] = rec[1];
+            if constexpr (D == 3) zj[q] = rec[2];
+            if constexpr (!UNIFORM) wj[q] = rec[3];
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -740,15 +767,15 @@ __global__ void __launch_bounds__(MD_TILE)
                 d2 = __builtin_fma(dz, dz, d2);
             }
             bool hit = d2 < pp.c2;
+            double d2m = mask_d2(d2, hit);
             double u = 0.0, fpr;
-            pair_eval<POT, UNIFORM, WANT_UW>(d2, pi.w, UNIFORM ? 0.0 : wj[q], pp, u, fpr);
-            fpr = hit ? fpr : 0.0;
+            pair_eval<POT, UNIFORM, WANT_UW>(d2m, pi.w, UNIFORM ? 0.0 : wj[q], pp, u, fpr);
             fx = __builtin_fma(-fpr, dx, fx);
             fy = __builtin_fma(-fpr, dy, fy);
             if constexpr (D == 3) fz = __builtin_fma(-fpr, dz, fz);
             if constexpr (WANT_UW) {
-                us += hit ? u : 0.0;
-                ws = __builtin_fma(fpr, d2, ws);
+                us += u;
+                ws = __builtin_fma(fpr, hit ? d2 : 0.0, ws);
             }
         }
     }
@@ -898,20 +925,20 @@ __global__ void k_set_scale(Scalars *sc, double v) { sc->scale = v; }
 template <int D>
 __global__ void __launch_bounds__(MD_BLOCK)
     k_pairs(int n, DevState s, double c2_inclusive, const uint32_t *__restrict__ nlist,
-            const uint16_t *__restrict__ nlist16, const uint32_t *__restrict__ halo, int hcap, int maxn,
+            const uint16_t *__restrict__ nlist16, int rs, const uint32_t *__restrict__ halo, int hcap, int maxn,
             const int32_t *__restrict__ nneigh, int32_t *__restrict__ out, unsigned long long cap, Scalars *sc)
 {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     int lane = threadIdx.x & 63, tile = k >> 6;
-    size_t rbase = ((size_t)tile * maxn) * 64 + lane;
+    size_t tbase = ((size_t)tile * maxn) * 64;
     const uint32_t *hl = halo + (size_t)(k / MD_TILE) * hcap;
     int cnt = nneigh[k];
     int a = s.id[k];
     double4 pk = s.pos[k];
     for (int r = 0; r < cnt; ++r) {
         // rows are either 32-bit global slots or 16-bit indices into the tile's halo list
-        uint32_t j = nlist16 ? hl[nlist16[rbase + (size_t)r * 64]] : nlist[rbase + (size_t)r * 64];
+        uint32_t j = nlist16 ? hl[nlist16[tbase + row_off(r, lane)] / (unsigned)rs] : nlist[tbase + lane + (size_t)r * 64];
         int b = s.id[j];
         if (a >= b) continue;
         double4 pj = s.pos[j];

@@ -111,6 +111,7 @@ struct md_ctx {
     int hstride = 0;       // LDS plane stride (doubles) of the last build
     size_t tile_lds = 0;   // dynamic LDS bytes of the tiled force kernel
     bool use_tiles = false;
+    int tile_rs = 24;
     bool allow_tiles = true;
     bool allow_fused_build = true;
     bool have_nlist32 = false; // the 32-bit global-index rows exist for the current build
@@ -276,6 +277,9 @@ void configure_potential(md_ctx *c)
     c->pp.c2 = c2;
     c->pp.sig_u = c->sigma_u;
     c->pp.sig2u = ((c->sigma_u + c->sigma_u) * 0.5) * ((c->sigma_u + c->sigma_u) * 0.5);
+    c->pp.c48 = 48.0 * c->pp.p[0];
+    c->pp.c24 = 24.0 * c->pp.p[0];
+    c->pp.c4 = 4.0 * c->pp.p[0];
 }
 
 void ensure_capacity(md_ctx *c, int64_t need_next)
@@ -362,14 +366,14 @@ void rebuild_t(md_ctx *c)
     c->use_tiles = false;
     c->have_nlist32 = false;
     bool tile_ok = false;
+    const int rs = (c->uniform_sigma && c->pot_kind != POT_POLYDISPERSE) ? 24 : 32; // LDS record stride of the tiled force kernel
     auto set_tiles = [&](const Scalars &h) {
-        int planes = c->uniform_sigma ? 3 : 4;
-        int stride = (h.hmax + 1 + 1) & ~1;
-        size_t bytes = (size_t)stride * 8 * planes;
+        size_t bytes = ((size_t)(h.hmax + 1) * rs + 15) & ~(size_t)15;
         if (!(h.halo_overflow) && bytes <= 150 * 1024) {
             c->use_tiles = true;
-            c->hstride = stride;
+            c->hstride = h.hmax;
             c->tile_lds = bytes;
+            c->tile_rs = rs;
             if (const char *e = getenv("MDHIP_LDS_PAD")) c->tile_lds += (size_t)atoi(e);
             return true;
         }
@@ -389,7 +393,7 @@ void rebuild_t(md_ctx *c)
             k_build_tile<D><<<c->nblk, MD_BT_THREADS, 0, st>>>(n, sn, g, rl2f, c->cell_start.p, c->cell_end.p,
                                                                c->nlist16.p, c->maxn, c->nneigh.p, c->nmax_tile.p,
                                                                c->halo.p, c->hcap, c->halo_count.p, c->scal.p,
-                                                               c->dbg_stamps.p);
+                                                               c->dbg_stamps.p, rs);
             if (c->dbg_stamps.p) {
                 std::vector<long long> hs((size_t)c->nblk * 10);
                 HIPCHK(hipMemcpyAsync(hs.data(), c->dbg_stamps.p, hs.size() * 8, hipMemcpyDeviceToHost, st));
@@ -439,7 +443,7 @@ void rebuild_t(md_ctx *c)
             }
             k_tile_localize<<<c->nblk, MD_TILE, lds, st>>>(c->nlist.p, c->nlist16.p, c->maxn, c->nmax_tile.p,
                                                            (uint32_t)c->cap, c->halo.p, c->hcap, c->halo_count.p,
-                                                           c->scal.p);
+                                                           c->scal.p, rs);
             Scalars h;
             HIPCHK(hipMemcpyAsync(&h, c->scal.p, sizeof(Scalars), hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
@@ -512,8 +516,8 @@ void launch_force_tpu(md_ctx *c, bool want_uw, bool kick, double dt, int step)
             attr_bytes = 160 * 1024;                                                                                \
         }                                                                                                           \
         kfn<<<nb, MD_TILE, c->tile_lds, c->stream>>>(n, s, c->pp, c->nlist16.p, c->maxn, c->nmax_tile.p, c->halo.p, \
-                                                     c->hcap, c->halo_count.p, c->hstride, dt, c->partials.p, nb,   \
-                                                     c->scal.p, step);                                              \
+                                                     c->hcap, c->halo_count.p, dt, c->partials.p, nb, c->scal.p,    \
+                                                     step);                                                         \
     } while (0)
     prof_begin(c);
     if (c->use_tiles) {
@@ -772,6 +776,7 @@ int md_set_potential(md_ctx *ctx, int kind, const double *params, int nparams)
     if (nparams < need) throw HipError("md_set_potential: too few parameters for this kind");
     for (int i = 0; i < 8; ++i) ctx->pp.p[i] = (i < nparams) ? params[i] : 0.0;
     ctx->pot_kind = kind;
+    ctx->list_valid = false; // the LDS record stride of the rows depends on the potential kind
     configure_potential(ctx);
     API_END
 }
@@ -913,11 +918,11 @@ int md_neighbor_pairs(md_ctx *ctx, int32_t *pairs, int64_t cap, int64_t *count)
     double c2 = ctx->rc * ctx->rc;
     const uint16_t *l16 = ctx->have_nlist32 ? nullptr : ctx->nlist16.p;
     if (ctx->dim == 3)
-        k_pairs<3><<<ctx->nblk, MD_BLOCK, 0, st>>>((int)ctx->n, s, c2, ctx->nlist.p, l16, ctx->halo.p, ctx->hcap,
+        k_pairs<3><<<ctx->nblk, MD_BLOCK, 0, st>>>((int)ctx->n, s, c2, ctx->nlist.p, l16, ctx->tile_rs, ctx->halo.p, ctx->hcap,
                                                    ctx->maxn, ctx->nneigh.p, out.p, (unsigned long long)cap,
                                                    ctx->scal.p);
     else
-        k_pairs<2><<<ctx->nblk, MD_BLOCK, 0, st>>>((int)ctx->n, s, c2, ctx->nlist.p, l16, ctx->halo.p, ctx->hcap,
+        k_pairs<2><<<ctx->nblk, MD_BLOCK, 0, st>>>((int)ctx->n, s, c2, ctx->nlist.p, l16, ctx->tile_rs, ctx->halo.p, ctx->hcap,
                                                    ctx->maxn, ctx->nneigh.p, out.p, (unsigned long long)cap,
                                                    ctx->scal.p);
     HIPCHK(hipGetLastError());
