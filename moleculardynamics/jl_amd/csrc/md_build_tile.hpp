@@ -50,19 +50,32 @@ __device__ __forceinline__ int block_excl_scan(int v, int *lds, int *total)
     return base + inc - v;
 }
 
-// One sweep of a thread's share [n0,n1) of the 27 (9) neighbour cells over the LDS image.
-// PASS 0 marks the staged particles the tile keeps; PASS 1 writes row entries starting at
-// `cnt0`.  Candidates are taken eight at a time with every LDS read of the batch issued
-// before the first use.
-template <int D, int PASS>
-__device__ __forceinline__ int tile_sweep(float xi, float yi, float zi, const int *ec, const BoxGrid &g, float rl2f,
-                                          int self_q, int n0, int n1, const float *px, const float *py,
-                                          const float *pz, const int *ucell, const int *coff, int nu,
-                                          unsigned char *ref, const uint16_t *newidx, uint16_t *row, int maxn,
-                                          int cnt0)
+// Sweep of a thread's share of the 27 (9) neighbour cells over the LDS image.  The cell loop is
+// fully unrolled (MD_HALF_CELLS iterations, cells beyond the thread's share are skipped) so
+// that the per-cell hit masks live in registers:
+//   tile_sweep_mark : tests d^2 <= rl^2 for every staged particle of each cell, eight at a
+//                     time, marks the particles the tile keeps (branch-free byte store; misses
+//                     write a trash slot), records one 64-bit hit mask per cell;
+//   tile_sweep_emit : walks the set bits only and writes the row entries -- no distance is
+//                     computed twice.
+// A cell holding more than 64 particles does not fit a mask: the tile reports overflow and the
+// host falls back to the two-kernel build.
+#define MD_HALF_CELLS 14
+
+template <int D>
+__device__ __forceinline__ int tile_sweep_mark(float xi, float yi, float zi, const int *ec, const BoxGrid &g,
+                                               float rl2f, int self_q, int n0, int n1, const float *px,
+                                               const float *py, const float *pz, const int *ucell, const int *coff,
+                                               int nu, unsigned char *ref, unsigned long long *mask, int *qstart,
+                                               bool *too_big)
 {
-    int cnt = cnt0;
-    for (int nbi = n0; nbi < n1; ++nbi) {
+    int cnt = 0;
+#pragma unroll
+    for (int ci = 0; ci < MD_HALF_CELLS; ++ci) {
+        mask[ci] = 0ull;
+        qstart[ci] = 0;
+        int nbi = n0 + ci;
+        if (nbi >= n1) continue;
         int dx = nbi % 3 - 1, dy = (nbi / 3) % 3 - 1, dz = (D == 3) ? nbi / 9 - 1 : 0;
         int e[3] = {ec[0] + dx, ec[1] + dy, (D == 3) ? ec[2] + dz : 0};
         int cell = ext_linear(e, g);
@@ -76,16 +89,20 @@ __device__ __forceinline__ int tile_sweep(float xi, float yi, float zi, const in
         }
         if (nu == 0 || ucell[lo] != cell) continue; // empty cell
         int qs = coff[lo], qe = coff[lo + 1];
+        if (qe - qs > 64) {
+            *too_big = true;
+            continue;
+        }
+        qstart[ci] = qs;
+        unsigned long long mk = 0ull;
         for (int q0 = qs; q0 < qe; q0 += MD_SWB) {
             float xq[MD_SWB], yq[MD_SWB], zq[MD_SWB];
-            uint32_t nq[MD_SWB];
 #pragma unroll
             for (int b = 0; b < MD_SWB; ++b) {
                 int q = min(q0 + b, qe - 1);
                 xq[b] = px[q];
                 yq[b] = py[q];
                 if constexpr (D == 3) zq[b] = pz[q];
-                if constexpr (PASS == 1) nq[b] = newidx[q];
             }
 #pragma unroll
             for (int b = 0; b < MD_SWB; ++b) {
@@ -98,15 +115,32 @@ __device__ __forceinline__ int tile_sweep(float xi, float yi, float zi, const in
                     float ddz = zq[b] - zi;
                     d2 = __builtin_fmaf(ddz, ddz, d2);
                 }
-                if (q < qe && d2 <= rl2f && q != self_q) {
-                    if constexpr (PASS == 0) {
-                        ref[q] = 1;
-                    } else {
-                        if (cnt < maxn) row[(size_t)cnt * 64] = (uint16_t)nq[b];
-                    }
-                    ++cnt;
-                }
+                bool hit = (q < qe) & (d2 <= rl2f) & (q != self_q);
+                ref[hit ? q : MD_SCAP - 1] = 1; // the last slot is never a particle (S < MD_SCAP)
+                mk |= (unsigned long long)(hit ? 1u : 0u) << (q - qs);
             }
+        }
+        mask[ci] = mk;
+        cnt += __popcll(mk);
+    }
+    return cnt;
+}
+
+__device__ __forceinline__ int tile_sweep_emit(const unsigned long long *mask, const int *qstart,
+                                               const uint16_t *newidx, uint16_t *rowbase, int lane, int maxn,
+                                               int cnt0, int rs)
+{
+    int cnt = cnt0;
+#pragma unroll
+    for (int ci = 0; ci < MD_HALF_CELLS; ++ci) {
+        unsigned long long mk = mask[ci];
+        int qs = qstart[ci];
+        while (mk) {
+            int b = __ffsll((long long)mk) - 1;
+            mk &= mk - 1ull;
+            unsigned v = (unsigned)newidx[qs + b] * (unsigned)rs;
+            if (cnt < maxn) rowbase[row_off(cnt, lane)] = (uint16_t)v;
+            ++cnt;
         }
     }
     return cnt;
@@ -117,7 +151,7 @@ __global__ void __launch_bounds__(MD_BT_THREADS)
     k_build_tile(int n, DevState s, BoxGrid g, float rl2f, const int32_t *__restrict__ cell_start,
                  const int32_t *__restrict__ cell_end, uint16_t *__restrict__ nlist16, int maxn,
                  int32_t *__restrict__ nneigh, int32_t *__restrict__ nmax_tile, uint32_t *__restrict__ halo, int hcap,
-                 int32_t *__restrict__ halo_count, Scalars *sc, long long *__restrict__ stamps)
+                 int32_t *__restrict__ halo_count, Scalars *sc, long long *__restrict__ stamps, int rs)
 {
 #define MD_STAMP(i)                                                                                   \
     do {                                                                                              \
@@ -240,7 +274,7 @@ __global__ void __launch_bounds__(MD_BT_THREADS)
         atomicMax(&sc->dbg_rmax, nne);
         atomicMax(&sc->dbg_smax, S);
     }
-    if (S > MD_SCAP) bad = true;
+    if (S >= MD_SCAP) bad = true; // the last slot is the trash slot of the mark sweep
     if (bad) {
         // this tile does not fit the fast path: the host falls back to the two-kernel build
         if (tid == 0) atomicOr(&sc->halo_overflow, 2);
@@ -278,14 +312,25 @@ __global__ void __launch_bounds__(MD_BT_THREADS)
     }
     __syncthreads();
     MD_STAMP(4);
-    // 3. sweep 0: mark + count
+    // 3. sweep: mark + per-cell hit masks
     const int wt = tile * (MD_TILE / 64) + (pt >> 6);
-    uint16_t *row = nlist16 + ((size_t)wt * maxn) * 64 + lane;
+    uint16_t *rowbase = nlist16 + ((size_t)wt * maxn) * 64;
     const int n0 = half ? nA : 0, n1 = half ? NNB : nA;
+    unsigned long long hmask[MD_HALF_CELLS];
+    int qstart[MD_HALF_CELLS];
     int cnt = 0;
+    bool too_big = false;
     if (active)
-        cnt = tile_sweep<D, 0>(xi, yi, zi, ec, g, rl2f, self_q, n0, n1, px, py, pz, ucell, coff, nu, ref, newidx, row,
-                               maxn, 0);
+        cnt = tile_sweep_mark<D>(xi, yi, zi, ec, g, rl2f, self_q, n0, n1, px, py, pz, ucell, coff, nu, ref, hmask,
+                                 qstart, &too_big);
+    else {
+#pragma unroll
+        for (int ci = 0; ci < MD_HALF_CELLS; ++ci) {
+            hmask[ci] = 0ull;
+            qstart[ci] = 0;
+        }
+    }
+    if (too_big) atomicOr(&sc->halo_overflow, 4);
     if (half == 0) cntA[pt] = cnt;
     __syncthreads();
     MD_STAMP(5);
@@ -294,11 +339,11 @@ __global__ void __launch_bounds__(MD_BT_THREADS)
     {
         const int per = MD_SCAP / MD_BT_THREADS;
         int c = 0;
-        for (int q = 0; q < per; ++q) c += ref[tid * per + q];
+        for (int q = 0; q < per; ++q) c += (tid * per + q < S) ? ref[tid * per + q] : 0;
         int run = block_excl_scan(c, sh_scan, &H);
         for (int q = 0; q < per; ++q) {
             int i = tid * per + q;
-            if (ref[i]) {
+            if (i < S && ref[i]) {
                 newidx[i] = (uint16_t)run;
                 if (run < hcap) {
                     int lo = 0, hi = nu;
@@ -317,18 +362,17 @@ __global__ void __launch_bounds__(MD_BT_THREADS)
         if (tid == 0) {
             halo_count[tile] = H;
             atomicMax(&sc->hmax, H);
-            if (H > hcap) atomicOr(&sc->halo_overflow, 1);
+            if (H > hcap || (H + 1) * rs > 65535) atomicOr(&sc->halo_overflow, 1);
         }
     }
     __syncthreads();
     MD_STAMP(6);
-    // 5. sweep 1: write the rows.  The second-half thread appends after the first half's entries.
+    // 5. emit: write the rows from the hit masks.  The second-half thread appends after the first
+    // half's entries.
     const int cA = cntA[pt];
     const int start = half ? cA : 0;
     int endc = start;
-    if (active)
-        endc = tile_sweep<D, 1>(xi, yi, zi, ec, g, rl2f, self_q, n0, n1, px, py, pz, ucell, coff, nu, ref, newidx, row,
-                                maxn, start);
+    if (active) endc = tile_sweep_emit(hmask, qstart, newidx, rowbase, lane, maxn, start, rs);
     __syncthreads();
     MD_STAMP(7);
     if (half == 1) cntA[pt] = endc; // total = cA + cB
@@ -345,7 +389,7 @@ __global__ void __launch_bounds__(MD_BT_THREADS)
         int m = wave_max_i(tot);
         m = (m + 3) & ~3;
         if (m > maxn) m = maxn;
-        for (int t = tot; t < m; ++t) row[(size_t)t * 64] = (uint16_t)H;
+        for (int t = tot; t < m; ++t) rowbase[row_off(t, lane)] = (uint16_t)(H * rs);
         if (lane == 0) nmax_tile[wt] = m;
     }
     MD_STAMP(8);
