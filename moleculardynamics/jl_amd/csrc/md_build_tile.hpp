@@ -66,8 +66,8 @@ template <int D>
 __device__ __forceinline__ int tile_sweep_mark(float xi, float yi, float zi, const int *ec, const BoxGrid &g,
                                                float rl2f, int self_q, int n0, int n1, const float *px,
                                                const float *py, const float *pz, const int *ucell, const int *coff,
-                                               int nu, unsigned char *ref, unsigned long long *mask, int *qstart,
-                                               bool *too_big)
+                                               int nu, unsigned char *ref, unsigned char *trash,
+                                               unsigned long long *mask, int *qstart, bool *too_big)
 {
     int cnt = 0;
 #pragma unroll
@@ -116,7 +116,10 @@ __device__ __forceinline__ int tile_sweep_mark(float xi, float yi, float zi, con
                     d2 = __builtin_fmaf(ddz, ddz, d2);
                 }
                 bool hit = (q < qe) & (d2 <= rl2f) & (q != self_q);
-                ref[hit ? q : MD_SCAP - 1] = 1; // the last slot is never a particle (S < MD_SCAP)
+                // misses write a per-lane trash byte (one shared trash byte would make ~55 lanes hit
+                // one LDS address per instruction)
+                unsigned char *dst = hit ? (ref + q) : trash;
+                *dst = 1;
                 mk |= (unsigned long long)(hit ? 1u : 0u) << (q - qs);
             }
         }
@@ -166,6 +169,7 @@ __global__ void __launch_bounds__(MD_BT_THREADS)
     __shared__ int sh_misc[4];
     __shared__ int sh_scan[16];
     __shared__ int sh_ne[MD_NEMAX];
+    __shared__ unsigned char sh_trash[4 * MD_BT_THREADS];
 
     const int tile = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -321,8 +325,8 @@ __global__ void __launch_bounds__(MD_BT_THREADS)
     int cnt = 0;
     bool too_big = false;
     if (active)
-        cnt = tile_sweep_mark<D>(xi, yi, zi, ec, g, rl2f, self_q, n0, n1, px, py, pz, ucell, coff, nu, ref, hmask,
-                                 qstart, &too_big);
+        cnt = tile_sweep_mark<D>(xi, yi, zi, ec, g, rl2f, self_q, n0, n1, px, py, pz, ucell, coff, nu, ref,
+                                 sh_trash + 4 * tid, hmask, qstart, &too_big);
     else {
 #pragma unroll
         for (int ci = 0; ci < MD_HALF_CELLS; ++ci) {
