@@ -176,7 +176,7 @@ def main():
                         f"{'NVT Bussi tau=0.1 kT=1.4737' if nvt else 'NVE'}, per GPU",
             "particles_per_gpu": a.n,
             "parallelism": "1 GPU" if world == 1 else f"{world} independent replicas (no data-path collective yet)",
-            "skin": a.skin if a.skin is not None else 0.3,
+            "skin": a.skin if a.skin is not None else 0.4,
             "rebuilds_in_timed_region": st1["rebuilds"] - st0["rebuilds"],
             "avg_list_candidates": st1["avg_neighbors"],
             "tiled_force_kernel": bool(st1["tiled"]),

@@ -84,7 +84,7 @@ struct md_ctx {
     int64_t n = 0;
     double L[3] = {1, 1, 1};
     double rc = 0.0;       // list cutoff (CellListMap's cutoff)
-    double skin_req = 0.3; // requested skin
+    double skin_req = 0.4; // requested skin (0.4 measured best for LJ r_c=2.5 at N=2^20: see DESIGN.md)
     double skin = 0.0;     // effective skin
     double rl = 0.0;       // rc + skin
     int pot_kind = POT_LJ;
