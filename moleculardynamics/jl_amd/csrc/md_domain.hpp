@@ -1,0 +1,239 @@
+// md_domain.hpp -- kernels of the 1-D slab decomposition (one handle per GPU, one slab of the
+// x axis per handle).  Particles migrate to the neighbour slabs at list builds; between builds
+// the owners of the particles within rc+skin of a slab face send their coordinates to the
+// neighbour every step, where they refresh the "x-halo" ghost copies.  y and z keep the
+// periodic self-image ghosts of the single-GPU path.  Transport lives outside the library
+// (torch.distributed: RCCL over xGMI on a multi-GPU node).
+#pragma once
+
+#define MD_MIG_REC 14 // x y z sigma | vx vy vz | fx fy fz | imgx imgy imgz | id      (doubles)
+#define MD_HALO_REC 5 // x y z sigma | id
+
+struct DomCounters {
+    int mig[2];   // migrants packed for the left / right neighbour
+    int halo[2];  // halo records packed for the left / right neighbour
+    int error;    // 1: a particle left by more than one slab, 2: a send buffer overflowed
+};
+
+// Wrap the owned particles (src/boundary.jl:7-17 arithmetic, all dimensions, global box),
+// decide which slab owns each one now, and pack the leavers' full state for the neighbour.
+template <int D>
+__global__ void __launch_bounds__(MD_BLOCK)
+    k_dom_classify(int n_old, DevState s, BoxGrid g, double xlo, double xhi, double inv_w, int rank, int nranks,
+                   int32_t *__restrict__ alive, double *__restrict__ sb0, double *__restrict__ sb1, int cap_rec,
+                   DomCounters *cnt)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_old) return;
+    double4 p = s.pos[i];
+    bool moved = false;
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        double xc = pos_get(p, c);
+        if (xc < 0.0 || xc >= g.L[c]) {
+            double frac = g.invL[c] * xc;
+            double nn = floor(frac);
+            s.img[c][i] += (int32_t)nn;
+            xc = g.L[c] * (frac - nn);
+            pos_set(p, c, xc);
+            moved = true;
+        }
+    }
+    if (moved) s.pos[i] = p;
+    int owner = (int)(p.x * inv_w);
+    owner = owner < 0 ? 0 : (owner > nranks - 1 ? nranks - 1 : owner);
+    if (owner == rank) {
+        alive[i] = 1;
+        return;
+    }
+    alive[i] = 0;
+    int d = owner - rank;
+    bool right = (d == 1) || (d == -(nranks - 1));
+    bool left = (d == -1) || (d == nranks - 1);
+    if (nranks == 2) {
+        // both neighbours are the same rank: route by the face that was crossed
+        double dl = xlo - p.x;
+        if (dl < 0.0) dl += g.L[0];
+        double dr = p.x - xhi;
+        if (dr < 0.0) dr += g.L[0];
+        left = dl < dr;
+        right = !left;
+    }
+    if (!left && !right) {
+        atomicOr(&cnt->error, 1);
+        return;
+    }
+    int side = right ? 1 : 0;
+    int j = atomicAdd(&cnt->mig[side], 1);
+    if (j >= cap_rec) {
+        atomicOr(&cnt->error, 2);
+        return;
+    }
+    double *r = (side ? sb1 : sb0) + (size_t)j * MD_MIG_REC;
+    r[0] = p.x;
+    r[1] = p.y;
+    r[2] = p.z;
+    r[3] = p.w;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        r[4 + c] = (c < D) ? s.v[c][i] : 0.0;
+        r[7 + c] = (c < D) ? s.f[c][i] : 0.0;
+        r[10 + c] = (c < D) ? (double)s.img[c][i] : 0.0;
+    }
+    r[13] = (double)s.id[i];
+}
+
+template <int D>
+__global__ void __launch_bounds__(MD_BLOCK)
+    k_dom_unpack_mig(int n, int base, const double *__restrict__ rb, DevState s, int32_t *__restrict__ alive)
+{
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const double *r = rb + (size_t)j * MD_MIG_REC;
+    int k = base + j;
+    s.pos[k] = make_double4(r[0], r[1], r[2], r[3]);
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        s.v[c][k] = r[4 + c];
+        s.f[c][k] = r[7 + c];
+        s.img[c][k] = (int32_t)r[10 + c];
+    }
+    s.id[k] = (int32_t)r[13];
+    alive[k] = 1;
+}
+
+// The live owned particles within rl of a slab face, translated into the neighbour's frame
+// when the face is the global periodic boundary.
+__global__ void __launch_bounds__(MD_BLOCK)
+    k_dom_select_halo(int n_own_src, DevState s, double xlo, double xhi, double rl, double shift_l, double shift_r,
+                      const int32_t *__restrict__ alive, double *__restrict__ sb0, double *__restrict__ sb1,
+                      int32_t *__restrict__ src0, int32_t *__restrict__ src1, int cap_rec, DomCounters *cnt)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_own_src || !alive[i]) return;
+    double4 p = s.pos[i];
+    double idv = (double)s.id[i];
+    if (p.x < xlo + rl) {
+        int j = atomicAdd(&cnt->halo[0], 1);
+        if (j < cap_rec) {
+            double *r = sb0 + (size_t)j * MD_HALO_REC;
+            r[0] = p.x + shift_l;
+            r[1] = p.y;
+            r[2] = p.z;
+            r[3] = p.w;
+            r[4] = idv;
+            src0[j] = i;
+        } else
+            atomicOr(&cnt->error, 2);
+    }
+    if (p.x >= xhi - rl) {
+        int j = atomicAdd(&cnt->halo[1], 1);
+        if (j < cap_rec) {
+            double *r = sb1 + (size_t)j * MD_HALO_REC;
+            r[0] = p.x + shift_r;
+            r[1] = p.y;
+            r[2] = p.z;
+            r[3] = p.w;
+            r[4] = idv;
+            src1[j] = i;
+        } else
+            atomicOr(&cnt->error, 2);
+    }
+}
+
+__global__ void __launch_bounds__(MD_BLOCK)
+    k_dom_unpack_halo(int n, int base, const double *__restrict__ rb, DevState s, int32_t *__restrict__ alive)
+{
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const double *r = rb + (size_t)j * MD_HALO_REC;
+    s.pos[base + j] = make_double4(r[0], r[1], r[2], r[3]);
+    s.id[base + j] = (int32_t)r[4];
+    alive[base + j] = 1;
+}
+
+__global__ void __launch_bounds__(MD_BLOCK)
+    k_dom_map_slots(int n, const int32_t *__restrict__ src, int src_base, const int32_t *__restrict__ newslot,
+                    int32_t *__restrict__ out)
+{
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    out[j] = newslot[src ? src[j] : src_base + j];
+}
+
+// per step: coordinates of the halo particles, in the order fixed at the build
+__global__ void __launch_bounds__(MD_BLOCK)
+    k_dom_pack_pos(int n, const int32_t *__restrict__ slot, const double4 *__restrict__ pos, double shift,
+                   double *__restrict__ out)
+{
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    double4 p = pos[slot[j]];
+    out[3 * (size_t)j + 0] = p.x + shift;
+    out[3 * (size_t)j + 1] = p.y;
+    out[3 * (size_t)j + 2] = p.z;
+}
+
+__global__ void __launch_bounds__(MD_BLOCK)
+    k_dom_unpack_pos(int n, const int32_t *__restrict__ slot, const double *__restrict__ in, double4 *__restrict__ pos)
+{
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    int k = slot[j];
+    double4 p = pos[k];
+    p.x = in[3 * (size_t)j + 0];
+    p.y = in[3 * (size_t)j + 1];
+    p.z = in[3 * (size_t)j + 2];
+    pos[k] = p;
+}
+
+// local-order transfer (slab handles exchange per-rank particle sets with the host)
+template <int D>
+__global__ void __launch_bounds__(MD_BLOCK)
+    k_import_local(int n, DevState s, const int32_t *__restrict__ ids, const double *__restrict__ xi,
+                   const double *__restrict__ vi, const double *__restrict__ fi, const int32_t *__restrict__ ii,
+                   const double *__restrict__ di)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    size_t o = (size_t)k * D;
+    double4 p = make_double4(0.0, 0.0, 0.0, di ? di[k] : 1.0);
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        pos_set(p, c, xi[o + c]);
+        s.v[c][k] = vi ? vi[o + c] : 0.0;
+        s.f[c][k] = fi ? fi[o + c] : 0.0;
+        s.img[c][k] = ii ? ii[o + c] : 0;
+    }
+    s.pos[k] = p;
+    s.id[k] = ids[k];
+}
+
+template <int D>
+__global__ void __launch_bounds__(MD_BLOCK)
+    k_export_local(int n, DevState s, BoxGrid g, int32_t *__restrict__ ids, double *__restrict__ xo,
+                   double *__restrict__ vo, double *__restrict__ fo, int32_t *__restrict__ io)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    size_t o = (size_t)k * D;
+    double4 p = s.pos[k];
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        double xc = pos_get(p, c);
+        int32_t im = s.img[c][k];
+        if (xc < 0.0 || xc >= g.L[c]) {
+            double frac = g.invL[c] * xc;
+            double nn = floor(frac);
+            im += (int32_t)nn;
+            xc = g.L[c] * (frac - nn);
+        }
+        xo[o + c] = xc;
+        io[o + c] = im;
+        vo[o + c] = s.v[c][k];
+        fo[o + c] = s.f[c][k];
+    }
+    ids[k] = s.id[k];
+}
+
+__global__ void k_reset_viol(Scalars *sc) { sc->first_viol = MD_NO_VIOLATION; }

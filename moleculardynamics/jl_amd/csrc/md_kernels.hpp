@@ -35,7 +35,10 @@ struct DevState {
 };
 
 struct BoxGrid {
-    double L[3], invL[3];
+    double L[3], invL[3];  // GLOBAL box lengths (wrapping, periodic translations)
+    double lo[3];          // origin of this handle's cell grid (slab decomposition: lo[0] = x_lo; else 0)
+    int selfimg[3];        // 1: the dimension is periodic within this handle (ghosts are self-images);
+                           // 0: its ghosts come from neighbour ranks (x under slab decomposition)
     double inv_cell[3];
     int nc[3];  // interior cells per dim
     int ncx[3]; // extended (ghost-padded) cells per dim; 1 for an unused dim
@@ -161,7 +164,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nb)
 template <int D>
 __device__ __forceinline__ int cell_coord(double xc, int c, const BoxGrid &g)
 {
-    int cc = (int)(xc * g.inv_cell[c]);
+    int cc = (int)((xc - g.lo[c]) * g.inv_cell[c]);
     cc = cc < 0 ? 0 : cc;
     cc = cc > g.nc[c] - 1 ? g.nc[c] - 1 : cc;
     return cc;
@@ -306,73 +309,103 @@ __device__ __forceinline__ void pos_set(double4 &p, int c, double v)
         p.z = v;
 }
 
+// Sources of a build: [0, n_own_src) particles this handle owns (some may be dead: they
+// migrated to a neighbour rank), [n_own_src, n_src) x-halo particles received from the
+// neighbour ranks (slab decomposition only).  Every live source emits one base entry plus one
+// entry per periodic self-image; entries of one source are consecutive (img_off = exclusive
+// scan of nimg), the radix sort then moves owned base entries to the front.
 template <int D>
-__global__ void __launch_bounds__(MD_BLOCK) k_wrap_count(int n, DevState s, BoxGrid g, int32_t *__restrict__ nimg)
+__device__ __forceinline__ void source_cells(const double4 &p, bool is_xh, const BoxGrid &g, int *e, int *b)
 {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    int cnt = 1;
-    double4 p = s.pos[i];
-    bool moved = false;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        e[c] = 0;
+        b[c] = 0;
+    }
 #pragma unroll
     for (int c = 0; c < D; ++c) {
         double xc = pos_get(p, c);
-        if (xc < 0.0 || xc >= g.L[c]) {
-            double frac = g.invL[c] * xc;
-            double nn = floor(frac);
-            double fm = frac - nn;
-            s.img[c][i] += (int32_t)nn;
-            xc = g.L[c] * fm;
-            pos_set(p, c, xc);
-            moved = true;
+        if (is_xh && !g.selfimg[c]) {
+            // a neighbour rank's particle: it sits in the ghost layer of the decomposed dimension
+            e[c] = (xc < g.lo[c]) ? 0 : g.nc[c] + 1;
+            continue;
         }
         int cc = cell_coord<D>(xc, c, g);
-        if (cc == 0 || cc == g.nc[c] - 1) cnt *= 2;
+        e[c] = cc + 1;
+        if (g.selfimg[c]) b[c] = (cc == 0) ? 1 : ((cc == g.nc[c] - 1) ? 2 : 0);
     }
-    if (moved) s.pos[i] = p;
-    nimg[i] = cnt - 1;
 }
 
-// stage 2: emit one sort entry per owned particle and per ghost copy.
-// key = [ghost bit | extended cell | original id]   val = [shift code (6 bits) | source slot]
 template <int D>
 __global__ void __launch_bounds__(MD_BLOCK)
-    k_emit(int n, DevState s, BoxGrid g, const int32_t *__restrict__ img_off, uint64_t *__restrict__ keys,
-           uint32_t *__restrict__ vals)
+    k_wrap_count(int n_src, int n_own_src, DevState s, BoxGrid g, const int32_t *__restrict__ alive,
+                 int32_t *__restrict__ nimg)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    int cc[3] = {0, 0, 0}, b[3] = {0, 0, 0};
-    double4 p = s.pos[i];
-#pragma unroll
-    for (int c = 0; c < D; ++c) {
-        cc[c] = cell_coord<D>(pos_get(p, c), c, g);
-        b[c] = (cc[c] == 0) ? 1 : ((cc[c] == g.nc[c] - 1) ? 2 : 0);
+    if (i >= n_src) return;
+    if (alive && !alive[i]) {
+        nimg[i] = 0;
+        return;
     }
-    uint64_t idv = (uint64_t)(uint32_t)s.id[i];
-    int e[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) e[c] = (c < D) ? cc[c] + 1 : 0;
-    keys[i] = ((uint64_t)ext_linear(e, g) << g.id_bits) | idv;
-    vals[i] = (uint32_t)i;
-    int slot = n + img_off[i];
-    uint64_t gbit = 1ull << (g.id_bits + g.cell_bits);
-    for (int m = 1; m < (1 << D); ++m) {
-        bool ok = true;
-        uint32_t code = 0;
+    bool is_xh = i >= n_own_src;
+    double4 p = s.pos[i];
+    if (!is_xh) {
+        bool moved = false;
 #pragma unroll
         for (int c = 0; c < D; ++c) {
-            int mc = (m >> c) & 1;
-            if (mc) {
+            double xc = pos_get(p, c);
+            if (xc < 0.0 || xc >= g.L[c]) {
+                double frac = g.invL[c] * xc;
+                double nn = floor(frac);
+                double fm = frac - nn;
+                s.img[c][i] += (int32_t)nn;
+                xc = g.L[c] * fm;
+                pos_set(p, c, xc);
+                moved = true;
+            }
+        }
+        if (moved) s.pos[i] = p;
+    }
+    int e[3], b[3];
+    source_cells<D>(p, is_xh, g, e, b);
+    int cnt = 1;
+#pragma unroll
+    for (int c = 0; c < D; ++c)
+        if (b[c]) cnt *= 2;
+    nimg[i] = cnt;
+}
+
+// key = [ghost bit | extended cell | original id]   val = [shift code (6 bits) | source index]
+template <int D>
+__global__ void __launch_bounds__(MD_BLOCK)
+    k_emit(int n_src, int n_own_src, DevState s, BoxGrid g, const int32_t *__restrict__ alive,
+           const int32_t *__restrict__ img_off, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_src) return;
+    if (alive && !alive[i]) return;
+    bool is_xh = i >= n_own_src;
+    double4 p = s.pos[i];
+    int eb[3], b[3];
+    source_cells<D>(p, is_xh, g, eb, b);
+    uint64_t idv = (uint64_t)(uint32_t)s.id[i];
+    uint64_t gbit = 1ull << (g.id_bits + g.cell_bits);
+    int slot = img_off[i];
+    for (int m = 0; m < (1 << D); ++m) {
+        bool ok = true;
+        uint32_t code = 0;
+        int e[3] = {eb[0], eb[1], eb[2]};
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            if ((m >> c) & 1) {
                 if (b[c] == 0) ok = false;
                 e[c] = (b[c] == 1) ? g.nc[c] + 1 : 0;
                 code |= (uint32_t)b[c] << (2 * c);
-            } else {
-                e[c] = cc[c] + 1;
             }
         }
         if (!ok) continue;
-        keys[slot] = gbit | ((uint64_t)ext_linear(e, g) << g.id_bits) | idv;
+        bool ghost = is_xh || m != 0;
+        keys[slot] = (ghost ? gbit : 0ull) | ((uint64_t)ext_linear(e, g) << g.id_bits) | idv;
         vals[slot] = (uint32_t)i | (code << MD_VAL_SRC_BITS);
         ++slot;
     }
@@ -416,11 +449,11 @@ __global__ void __launch_bounds__(MD_BLOCK)
             sn.img[c][k] = so.img[c][src];
             sn.x0[c][k] = pos_get(p, c);
         }
-        newslot[src] = k;
     } else {
         gsrc[k - n] = src;
         gcode[k - n] = code;
     }
+    if (code == 0u) newslot[src] = k; // base entry of a source (owned, or an x-halo copy in the ghost region)
     uint64_t cmask = (1ull << (g.cell_bits + 1)) - 1ull; // ghost bit kept: owned and ghost runs never merge
     int ce = (int)((key >> g.id_bits) & cmask);
     int cprev = (k > 0) ? (int)((keys[k - 1] >> g.id_bits) & cmask) : -1;

@@ -8,6 +8,7 @@
 #include <cstdlib>
 
 #include "md_kernels.hpp"
+#include "md_domain.hpp"
 
 #include <rocprim/rocprim.hpp>
 
@@ -81,7 +82,20 @@ std::string g_create_error;
 
 struct md_ctx {
     int dim = 3;
-    int64_t n = 0;
+    int64_t n = 0;        // particles this handle owns right now
+    int64_t ncap = 0;     // capacity of the per-owned arrays (== n for a single-GPU handle)
+    int64_t n_global = 0; // particles in the whole system (id range)
+    int64_t src_count = 0; // live entries of pos/id in the current buffer (sources of the next build)
+    // slab decomposition (md_create_domain); off for a single-GPU handle
+    struct Domain {
+        bool on = false;
+        int rank = 0, nranks = 1;
+        double xlo = 0.0, xhi = 0.0;
+        int64_t n_old = 0, n_arr = 0, n_xh = 0; // sources of the build in progress
+        int64_t nsend_mig[2] = {0, 0}, nsend_halo[2] = {0, 0}, nrecv_halo[2] = {0, 0};
+        DBuf<int32_t> alive, counters, hs_src[2], send_slot[2], xh_slot;
+        DBuf<double> sbuf[2], rbuf[2];
+    } dom;
     double L[3] = {1, 1, 1};
     double rc = 0.0;       // list cutoff (CellListMap's cutoff)
     double skin_req = 0.4; // requested skin (0.4 measured best for LJ r_c=2.5 at N=2^20: see DESIGN.md)
@@ -195,10 +209,10 @@ void alloc_state(md_ctx *c, int which, int64_t cap)
     StateBufs &b = c->sb[which];
     b.pos.alloc(cap + 1);
     for (int d = 0; d < c->dim; ++d) {
-        b.v[d].alloc(c->n);
-        b.f[d].alloc(c->n);
-        b.img[d].alloc(c->n);
-        b.x0[d].alloc(c->n);
+        b.v[d].alloc(c->ncap);
+        b.f[d].alloc(c->ncap);
+        b.img[d].alloc(c->ncap);
+        b.x0[d].alloc(c->ncap);
     }
     b.id.alloc(cap + 1);
 }
@@ -206,34 +220,45 @@ void alloc_state(md_ctx *c, int which, int64_t cap)
 // (re)derive the cell grid from box, cutoff and skin
 void configure_grid(md_ctx *c)
 {
-    double lmin = c->L[0];
-    for (int d = 1; d < c->dim; ++d) lmin = std::min(lmin, c->L[d]);
-    if (lmin / 3.0 < c->rc) {
+    // width of this handle's region per dimension (a slab handle owns [xlo, xhi) in x)
+    double W[3] = {c->L[0], c->L[1], c->L[2]};
+    if (c->dom.on) W[0] = c->dom.xhi - c->dom.xlo;
+    double lmin = 1e300;
+    for (int d = 0; d < c->dim; ++d) {
+        // a self-periodic dimension needs 3 cells (its two image layers must be distinct cells);
+        // the decomposed one needs 2
+        double need = (c->dom.on && d == 0) ? 2.0 : 3.0;
+        lmin = std::min(lmin, W[d] / need);
+    }
+    if (lmin < c->rc) {
         char b[256];
         snprintf(b, sizeof b,
-                 "box too small for the linked-cell build: need every box length >= 3*list_cutoff (L_min=%g, "
-                 "list_cutoff=%g)",
+                 "box too small for the linked-cell build: need every box length >= 3*list_cutoff (slab width >= "
+                 "2*list_cutoff); got limit %g for list_cutoff=%g",
                  lmin, c->rc);
         throw HipError(b);
     }
     double skin = std::max(0.0, c->skin_req);
-    double smax = lmin / 3.0 - c->rc;
+    double smax = lmin - c->rc;
     if (skin > smax) skin = std::max(0.0, smax * 0.999);
     c->skin = skin;
     c->rl = c->rc + skin;
     BoxGrid &g = c->grid;
     int64_t ncell = 1;
     for (int d = 0; d < 3; ++d) {
+        g.lo[d] = 0.0;
+        g.selfimg[d] = 1;
         if (d < c->dim) {
             g.L[d] = c->L[d];
             g.invL[d] = 1.0 / c->L[d];
-            int k = (int)std::floor(c->L[d] / c->rl);
+            int kmin = (c->dom.on && d == 0) ? 2 : 3;
+            int k = (int)std::floor(W[d] / c->rl);
             // guard against floor() landing one too high through rounding
-            while (k > 3 && c->L[d] / k < c->rl) --k;
-            if (k < 3) k = 3;
+            while (k > kmin && W[d] / k < c->rl) --k;
+            if (k < kmin) k = kmin;
             g.nc[d] = k;
             g.ncx[d] = k + 2;
-            g.inv_cell[d] = (double)k / c->L[d];
+            g.inv_cell[d] = (double)k / W[d];
         } else {
             g.L[d] = 1.0;
             g.invL[d] = 1.0;
@@ -241,6 +266,10 @@ void configure_grid(md_ctx *c)
             g.ncx[d] = 1;
             g.inv_cell[d] = 0.0;
         }
+    }
+    if (c->dom.on) {
+        g.lo[0] = c->dom.xlo;
+        g.selfimg[0] = 0;
     }
     // brick-major cell numbering: balanced bricks of about 2x2x3 cells (4x3 in 2-D)
     int target[3] = {2, 2, 3};
@@ -258,7 +287,7 @@ void configure_grid(md_ctx *c)
     g.n_int_cells = (int)nint;
     if (ncell > (1ll << 30)) throw HipError("cell grid too large");
     c->ncell_ext = (int)ncell;
-    g.id_bits = std::max(1, ceil_log2((uint64_t)c->n));
+    g.id_bits = std::max(1, ceil_log2((uint64_t)std::max<int64_t>(c->n_global, 2)));
     g.cell_bits = std::max(1, ceil_log2((uint64_t)ncell));
     c->cell_start.ensure(ncell + 1);
     c->cell_end.ensure(ncell + 1);
@@ -294,8 +323,9 @@ void ensure_capacity(md_ctx *c, int64_t need_next)
         DBuf<int32_t> ni;
         ni.alloc(newcap + 1);
         if (w == c->cur) {
-            HIPCHK(hipMemcpyAsync(np.p, b.pos.p, sizeof(double4) * c->n, hipMemcpyDeviceToDevice, c->stream));
-            HIPCHK(hipMemcpyAsync(ni.p, b.id.p, sizeof(int32_t) * c->n, hipMemcpyDeviceToDevice, c->stream));
+            int64_t keep = std::max(c->n, c->src_count);
+            HIPCHK(hipMemcpyAsync(np.p, b.pos.p, sizeof(double4) * keep, hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(hipMemcpyAsync(ni.p, b.id.p, sizeof(int32_t) * keep, hipMemcpyDeviceToDevice, c->stream));
         }
         double4 sent = make_double4(MD_SENTINEL_POS, MD_SENTINEL_POS, c->dim == 3 ? MD_SENTINEL_POS : 0.0, 1.0);
         int32_t m1 = -1;
@@ -312,37 +342,53 @@ void ensure_capacity(md_ctx *c, int64_t need_next)
     c->keys_out.ensure(newcap);
     c->vals_in.ensure(newcap);
     c->vals_out.ensure(newcap);
-    c->gsrc.ensure(newcap - c->n + 1);
-    c->gcode.ensure(newcap - c->n + 1);
-    c->gowner.ensure(newcap - c->n + 1);
+    c->gsrc.ensure(newcap + 1);
+    c->gcode.ensure(newcap + 1);
+    c->gowner.ensure(newcap + 1);
+    c->nimg.ensure(newcap + 2);
+    c->img_off.ensure(newcap + 2);
+    c->newslot.ensure(newcap + 1);
 }
 
 template <int D>
 void rebuild_t(md_ctx *c)
 {
     hipStream_t st = c->stream;
-    int n = (int)c->n;
-    int nb = nblocks(n);
+    // sources of this build: a single-GPU handle sorts its n particles; a slab handle sorts the
+    // survivors of [0, n_old) plus arrivals, plus the x-halo copies received from its neighbours
+    const bool dom = c->dom.on;
+    const int n_own_src = dom ? (int)(c->dom.n_old + c->dom.n_arr) : (int)c->n;
+    const int n_src = dom ? (int)(n_own_src + c->dom.n_xh) : (int)c->n;
+    const int32_t *alive = dom ? c->dom.alive.p : nullptr;
+    int64_t n_new = dom ? (c->dom.n_old - c->dom.nsend_mig[0] - c->dom.nsend_mig[1] + c->dom.n_arr) : c->n;
+    if (n_new > c->ncap) throw HipError("owned-particle capacity exceeded (slab handle: raise n_cap)");
+    c->src_count = n_src;
+    ensure_capacity(c, n_src + 1);
+    int nbs = nblocks(n_src);
     DevState so = c->dev(c->cur);
     BoxGrid g = c->grid;
 
-    k_wrap_count<D><<<nb, MD_BLOCK, 0, st>>>(n, so, g, c->nimg.p);
-    // exclusive scan over n+1 items (nimg[n] == 0 by construction) -> img_off[n] = #ghosts
+    k_wrap_count<D><<<nbs, MD_BLOCK, 0, st>>>(n_src, n_own_src, so, g, alive, c->nimg.p);
+    HIPCHK(hipMemsetAsync(c->nimg.p + n_src, 0, sizeof(int32_t), st));
+    // exclusive scan over n_src+1 items -> img_off[n_src] = total number of sort entries
     size_t tmp_bytes = 0;
-    HIPCHK(rocprim::exclusive_scan(nullptr, tmp_bytes, c->nimg.p, c->img_off.p, (int32_t)0, (size_t)n + 1,
+    HIPCHK(rocprim::exclusive_scan(nullptr, tmp_bytes, c->nimg.p, c->img_off.p, (int32_t)0, (size_t)n_src + 1,
                                    rocprim::plus<int32_t>(), st));
     c->scan_tmp.ensure(tmp_bytes);
-    HIPCHK(rocprim::exclusive_scan(c->scan_tmp.p, tmp_bytes, c->nimg.p, c->img_off.p, (int32_t)0, (size_t)n + 1,
+    HIPCHK(rocprim::exclusive_scan(c->scan_tmp.p, tmp_bytes, c->nimg.p, c->img_off.p, (int32_t)0, (size_t)n_src + 1,
                                    rocprim::plus<int32_t>(), st));
-    int32_t nghost = 0;
-    HIPCHK(hipMemcpyAsync(&nghost, c->img_off.p + n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    int32_t total = 0;
+    HIPCHK(hipMemcpyAsync(&total, c->img_off.p + n_src, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    int64_t next = (int64_t)n + nghost;
+    int64_t next = total;
+    int n = (int)n_new;
+    int32_t nghost = (int32_t)(next - n_new);
+    if (nghost < 0) throw HipError("internal: fewer sort entries than owned particles");
     ensure_capacity(c, next);
     so = c->dev(c->cur);
     DevState sn = c->dev(c->cur ^ 1);
 
-    k_emit<D><<<nb, MD_BLOCK, 0, st>>>(n, so, g, c->img_off.p, c->keys_in.p, c->vals_in.p);
+    k_emit<D><<<nbs, MD_BLOCK, 0, st>>>(n_src, n_own_src, so, g, alive, c->img_off.p, c->keys_in.p, c->vals_in.p);
     unsigned end_bit = (unsigned)(g.id_bits + g.cell_bits + 1);
     tmp_bytes = 0;
     HIPCHK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, c->keys_in.p, c->keys_out.p, c->vals_in.p, c->vals_out.p,
@@ -360,6 +406,10 @@ void rebuild_t(md_ctx *c)
     c->cur ^= 1;
     c->next = next;
     c->nghost = nghost;
+    c->n = n_new;
+    c->nblk = nblocks(n_new);
+    c->src_count = n_new;
+    int nb = c->nblk;
 
     // neighbour rows
     double rl2 = c->rl * c->rl;
@@ -653,15 +703,21 @@ const char *md_version(void) { return "mdhip 0.1 gfx950"; }
 
 const char *md_last_error(md_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
-int md_create(int dim, int64_t n_particles, const double *box, double list_cutoff, int device_id, md_ctx **out)
+static int create_common(int dim, int64_t n_global, int64_t n_cap, bool domain, int rank, int nranks,
+                         const double *box, double list_cutoff, int device_id, md_ctx **out)
 {
     if (!out) return fail(nullptr, "md_create: out is null");
     *out = nullptr;
     if (dim != 2 && dim != 3) return fail(nullptr, "md_create: dim must be 2 or 3");
-    if (n_particles < 2) return fail(nullptr, "md_create: need at least 2 particles");
-    if (n_particles >= (int64_t)MD_VAL_SRC_MASK) return fail(nullptr, "md_create: too many particles for one handle (limit 2^26-1)");
+    if (n_global < 2) return fail(nullptr, "md_create: need at least 2 particles");
+    if (n_cap < 2) return fail(nullptr, "md_create: capacity must be at least 2");
+    if (n_cap >= (int64_t)MD_VAL_SRC_MASK / 2)
+        return fail(nullptr, "md_create: too many particles for one handle (limit 2^25)");
+    if (n_global >= (1ll << 31)) return fail(nullptr, "md_create: particle ids must fit 31 bits");
     if (!box) return fail(nullptr, "md_create: box is null");
     if (!(list_cutoff > 0.0)) return fail(nullptr, "md_create: list_cutoff must be positive");
+    if (domain && (nranks < 2 || rank < 0 || rank >= nranks))
+        return fail(nullptr, "md_create_domain: need nranks >= 2 and 0 <= rank < nranks");
     for (int r = 0; r < dim; ++r)
         for (int c = 0; c < dim; ++c) {
             double v = box[c * dim + r];
@@ -681,9 +737,18 @@ int md_create(int dim, int64_t n_particles, const double *box, double list_cutof
         HIPCHK(hipSetDevice(device_id));
         HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
         ctx->dim = dim;
-        ctx->n = n_particles;
+        ctx->n_global = n_global;
+        ctx->ncap = n_cap;
+        ctx->n = domain ? 0 : n_cap;
         for (int c = 0; c < dim; ++c) ctx->L[c] = box[c * dim + c];
         ctx->rc = list_cutoff;
+        if (domain) {
+            ctx->dom.on = true;
+            ctx->dom.rank = rank;
+            ctx->dom.nranks = nranks;
+            ctx->dom.xlo = ctx->L[0] * rank / nranks;
+            ctx->dom.xhi = (rank == nranks - 1) ? ctx->L[0] : ctx->L[0] * (rank + 1) / nranks;
+        }
         if (const char *e = getenv("MDHIP_NO_TILES")) ctx->allow_tiles = !(e[0] == '1');
         if (const char *e = getenv("MDHIP_NO_FUSED_BUILD")) ctx->allow_fused_build = !(e[0] == '1');
         // default potential: LennardJones() -- src/potentials.jl:52-64
@@ -693,42 +758,43 @@ int md_create(int dim, int64_t n_particles, const double *box, double list_cutof
         ctx->pp.p[2] = 2.5;
         configure_grid(ctx);
         configure_potential(ctx);
-        // capacity: owned + ghost shell estimate
+        // capacity: owned + ghost shell estimate (self-images, and the neighbours' halo for a slab)
         double frac = 1.0;
         for (int c = 0; c < dim; ++c) frac *= (double)ctx->grid.ncx[c] / ctx->grid.nc[c];
-        int64_t gcap = (int64_t)((frac - 1.0) * 1.3 * n_particles) + 4096;
-        ctx->cap = n_particles + gcap;
+        int64_t gcap = (int64_t)((frac - 1.0) * 1.3 * n_cap) + 4096;
+        ctx->cap = n_cap + gcap;
         alloc_state(ctx, 0, ctx->cap);
         alloc_state(ctx, 1, ctx->cap);
-        int64_t n = n_particles;
-        ctx->nimg.alloc(n + 1);
-        ctx->img_off.alloc(n + 1);
-        HIPCHK(hipMemsetAsync(ctx->nimg.p, 0, sizeof(int32_t) * (n + 1), ctx->stream));
-        ctx->newslot.alloc(n);
+        int64_t n = n_cap;
+        ctx->nimg.alloc(ctx->cap + 2);
+        ctx->img_off.alloc(ctx->cap + 2);
+        HIPCHK(hipMemsetAsync(ctx->nimg.p, 0, sizeof(int32_t) * (ctx->cap + 2), ctx->stream));
+        ctx->newslot.alloc(ctx->cap + 1);
         ctx->keys_in.alloc(ctx->cap);
         ctx->keys_out.alloc(ctx->cap);
         ctx->vals_in.alloc(ctx->cap);
         ctx->vals_out.alloc(ctx->cap);
-        ctx->gsrc.alloc(gcap + 1);
-        ctx->gcode.alloc(gcap + 1);
-        ctx->gowner.alloc(gcap + 1);
-        ctx->nblk = nblocks(n);
-        ctx->ntiles = (int64_t)ctx->nblk * (MD_BLOCK / 64);
+        ctx->gsrc.alloc(ctx->cap + 1);
+        ctx->gcode.alloc(ctx->cap + 1);
+        ctx->gowner.alloc(ctx->cap + 1);
+        ctx->nblk = nblocks(ctx->n);
+        int nblk_cap = nblocks(n);
+        ctx->ntiles = (int64_t)nblk_cap * (MD_BLOCK / 64);
         ctx->nneigh.alloc(n);
         ctx->nmax_tile.alloc(ctx->ntiles);
         // expected neighbours within rc+skin at this density, with headroom
-        double dens = (double)n;
+        double dens = (double)n_global;
         for (int c = 0; c < dim; ++c) dens /= ctx->L[c];
         double vol = (dim == 3) ? 4.18879020478639 * ctx->rl * ctx->rl * ctx->rl : 3.14159265358979 * ctx->rl * ctx->rl;
         int maxn = (int)(dens * vol * 1.35) + 24;
         ctx->maxn = (maxn + 3) & ~3;
         ctx->nlist.alloc((size_t)ctx->ntiles * ctx->maxn * 64);
         ctx->nlist16.alloc((size_t)ctx->ntiles * ctx->maxn * 64);
-        ctx->halo.alloc((size_t)ctx->nblk * ctx->hcap);
-        ctx->halo_count.alloc(ctx->nblk);
-        if (getenv("MDHIP_STAMPS")) ctx->dbg_stamps.alloc((size_t)ctx->nblk * 10);
-        ctx->partials.alloc((size_t)3 * ctx->nblk);
-        HIPCHK(hipMemsetAsync(ctx->partials.p, 0, sizeof(double) * 3 * ctx->nblk, ctx->stream));
+        ctx->halo.alloc((size_t)nblk_cap * ctx->hcap);
+        ctx->halo_count.alloc(nblk_cap);
+        if (getenv("MDHIP_STAMPS")) ctx->dbg_stamps.alloc((size_t)nblk_cap * 10);
+        ctx->partials.alloc((size_t)3 * nblk_cap);
+        HIPCHK(hipMemsetAsync(ctx->partials.p, 0, sizeof(double) * 3 * nblk_cap, ctx->stream));
         ctx->scal.alloc(1);
         Scalars h{};
         h.scale = 1.0;
@@ -737,6 +803,18 @@ int md_create(int dim, int64_t n_particles, const double *box, double list_cutof
         ctx->d_kt.alloc(1);
         ctx->d_r1.alloc(1);
         ctx->d_r2.alloc(1);
+        if (domain) {
+            int64_t rec_cap = n_cap / 2 + 8192;
+            ctx->dom.alive.alloc(ctx->cap + 2);
+            ctx->dom.counters.alloc(8);
+            for (int sd = 0; sd < 2; ++sd) {
+                ctx->dom.sbuf[sd].alloc((size_t)rec_cap * MD_MIG_REC);
+                ctx->dom.rbuf[sd].alloc((size_t)rec_cap * MD_MIG_REC);
+                ctx->dom.hs_src[sd].alloc(rec_cap);
+                ctx->dom.send_slot[sd].alloc(rec_cap);
+            }
+            ctx->dom.xh_slot.alloc(2 * rec_cap);
+        }
         for (int w = 0; w < 2; ++w)
             k_init_state<<<nblocks(ctx->cap + 1), MD_BLOCK, 0, ctx->stream>>>((int)n, ctx->cap, ctx->dev(w), dim);
         HIPCHK(hipGetLastError());
@@ -748,6 +826,17 @@ int md_create(int dim, int64_t n_particles, const double *box, double list_cutof
     }
     *out = ctx;
     return 0;
+}
+
+int md_create(int dim, int64_t n_particles, const double *box, double list_cutoff, int device_id, md_ctx **out)
+{
+    return create_common(dim, n_particles, n_particles, false, 0, 1, box, list_cutoff, device_id, out);
+}
+
+int md_create_domain(int dim, int64_t n_global, int64_t n_cap, const double *box, double list_cutoff,
+                     int device_id, int rank, int nranks, md_ctx **out)
+{
+    return create_common(dim, n_global, n_cap, true, rank, nranks, box, list_cutoff, device_id, out);
 }
 
 int md_destroy(md_ctx *ctx)
@@ -801,7 +890,7 @@ int md_set_skin(md_ctx *ctx, double skin)
     double old_rl = ctx->rl;
     configure_grid(ctx);
     if (ctx->rl > old_rl) {
-        double dens = (double)ctx->n;
+        double dens = (double)ctx->n_global;
         for (int c = 0; c < ctx->dim; ++c) dens /= ctx->L[c];
         double vol = (ctx->dim == 3) ? 4.18879020478639 * ctx->rl * ctx->rl * ctx->rl
                                      : 3.14159265358979 * ctx->rl * ctx->rl;
