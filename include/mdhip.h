@@ -121,6 +121,44 @@ typedef struct {
 int md_profile(md_ctx *ctx, int enable);
 int md_get_stats(md_ctx *ctx, md_stats *out);
 
+/* ---------------------------------------------------------------------------------------------
+ * Slab decomposition: one handle per GPU, each owning the particles of one slab of the x axis
+ * (new relative to the reference, which is single-process).  y and z
+ * stay periodic inside the handle; x-direction ghosts are copies of the neighbour slabs'
+ * particles.  The library packs and unpacks; the CALLER moves the buffers between the ranks
+ * (moleculardynamics/jl_amd/domain.py does it with torch.distributed: RCCL over xGMI).
+ *
+ * A list build is the sequence  migrate_pack -> [exchange] -> migrate_unpack -> halo_pack ->
+ * [exchange] -> halo_unpack -> build ; a step is  step_begin -> [exchange] -> step_end .
+ * side 0 = the left neighbour (rank-1 mod P), side 1 = the right neighbour.  A message sent
+ * to side s arrives in the neighbour's receive buffer 1-s.  Record sizes in doubles:
+ * migrants 14, halo records 5, per-step halo coordinates 3.
+ * ------------------------------------------------------------------------------------------- */
+int md_create_domain(int dim, int64_t n_global, int64_t n_cap, const double *box, double list_cutoff,
+                     int device_id, int rank, int nranks, md_ctx **out);
+int md_dom_set_uniform(md_ctx *ctx, int uniform, double sigma);
+/* per-rank state in local order: row k of x/v/f/images belongs to particle ids[k] */
+int md_dom_upload(md_ctx *ctx, int64_t n_own, const int32_t *ids, const double *x, const double *v, const double *f,
+                  const int32_t *images, const double *diameters);
+int md_dom_download(md_ctx *ctx, int64_t cap, int64_t *n_own, int32_t *ids, double *x, double *v, double *f,
+                    int32_t *images);
+int md_dom_migrate_pack(md_ctx *ctx, int64_t *nsend /* [2] */);
+int md_dom_migrate_unpack(md_ctx *ctx, const int64_t *nrecv /* [2] */);
+int md_dom_halo_pack(md_ctx *ctx, int64_t *nsend /* [2] */);
+int md_dom_halo_unpack(md_ctx *ctx, const int64_t *nrecv /* [2] */);
+int md_dom_build(md_ctx *ctx);
+int md_dom_get_sendbuf(md_ctx *ctx, int side, int64_t ndoubles, void *dst, int dst_is_device);
+int md_dom_put_recvbuf(md_ctx *ctx, int side, int64_t ndoubles, const void *src, int src_is_device);
+/* first half of a step (pending Bussi rescale, half-kick, drift; src/integrate.jl:8-21); *violated = 1 if
+ * some particle of this rank moved skin/2 since the build: every rank must then rebuild before forces */
+int md_dom_step_begin(md_ctx *ctx, double dt, int *violated);
+/* second half (ghost refresh, forces, second half-kick; src/integrate.jl:28-38); uwk = this rank's {U, W, K} */
+int md_dom_step_end(md_ctx *ctx, double dt, int want_uw, double *uwk);
+int md_dom_forces(md_ctx *ctx, double dt, int kick, int want_uw, double *uwk);
+/* velocity scale to apply in front of the next half-kick (bussi!'s rescale, src/thermostat.jl:43-45) */
+int md_dom_set_scale(md_ctx *ctx, double scale);
+int md_dom_counts(md_ctx *ctx, int64_t *out /* [6]: n_own, nsend_halo L,R, nrecv_halo L,R, n_ghost */);
+
 /* Library build info: returns e.g. "mdhip 0.1 gfx950". */
 const char *md_version(void);
 

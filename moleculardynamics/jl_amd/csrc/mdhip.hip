@@ -805,7 +805,7 @@ static int create_common(int dim, int64_t n_global, int64_t n_cap, bool domain, 
         ctx->d_r2.alloc(1);
         if (domain) {
             int64_t rec_cap = n_cap / 2 + 8192;
-            ctx->dom.alive.alloc(ctx->cap + 2);
+            ctx->dom.alive.alloc(2 * ctx->cap + 2);
             ctx->dom.counters.alloc(8);
             for (int sd = 0; sd < 2; ++sd) {
                 ctx->dom.sbuf[sd].alloc((size_t)rec_cap * MD_MIG_REC);
@@ -1187,6 +1187,396 @@ int md_get_stats(md_ctx *ctx, md_stats *out)
     out->tiled = ctx->use_tiles ? 1 : 0;
     out->force_launches = ctx->prof_launch_acc;
     out->force_ms = ctx->prof_ms_acc;
+    API_END
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Slab decomposition entry points (see include/mdhip.h).  The caller (one process per GPU)
+// moves the packed buffers between ranks; everything else happens on the device.
+// ------------------------------------------------------------------------------------------
+namespace {
+void dom_require(md_ctx *c)
+{
+    if (!c->dom.on) throw HipError("this handle was not created with md_create_domain");
+}
+DomCounters dom_read_counters(md_ctx *c)
+{
+    DomCounters h;
+    HIPCHK(hipMemcpyAsync(&h, c->dom.counters.p, sizeof h, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (h.error & 1) throw HipError("a particle moved by more than one slab between list builds");
+    if (h.error & 2) throw HipError("slab exchange buffer overflow (raise n_cap)");
+    return h;
+}
+} // namespace
+
+int md_dom_set_uniform(md_ctx *ctx, int uniform, double sigma)
+{
+    API_BEGIN
+    dom_require(ctx);
+    ctx->uniform_sigma = uniform != 0;
+    ctx->sigma_u = sigma;
+    configure_potential(ctx);
+    ctx->list_valid = false;
+    API_END
+}
+
+int md_dom_upload(md_ctx *ctx, int64_t n_own, const int32_t *ids, const double *x, const double *v, const double *f,
+                  const int32_t *images, const double *diameters)
+{
+    API_BEGIN
+    dom_require(ctx);
+    if (n_own < 0 || n_own > ctx->ncap) throw HipError("md_dom_upload: n_own exceeds the handle's capacity");
+    if (n_own > 0 && (!ids || !x)) throw HipError("md_dom_upload: ids and x are required");
+    size_t nd = (size_t)n_own * ctx->dim;
+    hipStream_t st = ctx->stream;
+    DBuf<int32_t> d_ids;
+    d_ids.alloc(n_own + 1);
+    ctx->io_x.ensure(nd + 1);
+    ctx->io_v.ensure(nd + 1);
+    ctx->io_f.ensure(nd + 1);
+    ctx->io_i.ensure(nd + 1);
+    ctx->io_d.ensure(n_own + 1);
+    if (n_own > 0) {
+        HIPCHK(hipMemcpyAsync(d_ids.p, ids, n_own * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(ctx->io_x.p, x, nd * sizeof(double), hipMemcpyHostToDevice, st));
+        if (v) HIPCHK(hipMemcpyAsync(ctx->io_v.p, v, nd * sizeof(double), hipMemcpyHostToDevice, st));
+        if (f) HIPCHK(hipMemcpyAsync(ctx->io_f.p, f, nd * sizeof(double), hipMemcpyHostToDevice, st));
+        if (images) HIPCHK(hipMemcpyAsync(ctx->io_i.p, images, nd * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        if (diameters) HIPCHK(hipMemcpyAsync(ctx->io_d.p, diameters, n_own * sizeof(double), hipMemcpyHostToDevice, st));
+        DevState s = ctx->dev(ctx->cur);
+        int nb = nblocks(n_own);
+        if (ctx->dim == 3)
+            k_import_local<3><<<nb, MD_BLOCK, 0, st>>>((int)n_own, s, d_ids.p, ctx->io_x.p, v ? ctx->io_v.p : nullptr,
+                                                       f ? ctx->io_f.p : nullptr, images ? ctx->io_i.p : nullptr,
+                                                       diameters ? ctx->io_d.p : nullptr);
+        else
+            k_import_local<2><<<nb, MD_BLOCK, 0, st>>>((int)n_own, s, d_ids.p, ctx->io_x.p, v ? ctx->io_v.p : nullptr,
+                                                       f ? ctx->io_f.p : nullptr, images ? ctx->io_i.p : nullptr,
+                                                       diameters ? ctx->io_d.p : nullptr);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    ctx->n = n_own;
+    ctx->nblk = nblocks(n_own);
+    ctx->src_count = n_own;
+    ctx->list_valid = false;
+    API_END
+}
+
+int md_dom_download(md_ctx *ctx, int64_t cap, int64_t *n_own, int32_t *ids, double *x, double *v, double *f,
+                    int32_t *images)
+{
+    API_BEGIN
+    dom_require(ctx);
+    if (n_own) *n_own = ctx->n;
+    if (cap < ctx->n) throw HipError("md_dom_download: output capacity is smaller than the owned count");
+    int64_t n = ctx->n;
+    if (n == 0) return 0;
+    size_t nd = (size_t)n * ctx->dim;
+    hipStream_t st = ctx->stream;
+    DBuf<int32_t> d_ids;
+    d_ids.alloc(n);
+    ctx->io_x.ensure(nd);
+    ctx->io_v.ensure(nd);
+    ctx->io_f.ensure(nd);
+    ctx->io_i.ensure(nd);
+    DevState s = ctx->dev(ctx->cur);
+    if (ctx->dim == 3)
+        k_export_local<3><<<nblocks(n), MD_BLOCK, 0, st>>>((int)n, s, ctx->grid, d_ids.p, ctx->io_x.p, ctx->io_v.p,
+                                                           ctx->io_f.p, ctx->io_i.p);
+    else
+        k_export_local<2><<<nblocks(n), MD_BLOCK, 0, st>>>((int)n, s, ctx->grid, d_ids.p, ctx->io_x.p, ctx->io_v.p,
+                                                           ctx->io_f.p, ctx->io_i.p);
+    HIPCHK(hipGetLastError());
+    if (ids) HIPCHK(hipMemcpyAsync(ids, d_ids.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    if (x) HIPCHK(hipMemcpyAsync(x, ctx->io_x.p, nd * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (v) HIPCHK(hipMemcpyAsync(v, ctx->io_v.p, nd * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (f) HIPCHK(hipMemcpyAsync(f, ctx->io_f.p, nd * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (images) HIPCHK(hipMemcpyAsync(images, ctx->io_i.p, nd * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    API_END
+}
+
+// step 1 of a list build: wrap, decide ownership, pack the leavers.  nsend[2] = records for the
+// left / right neighbour (MD_MIG_REC doubles each) now sitting in the send buffers.
+int md_dom_migrate_pack(md_ctx *ctx, int64_t *nsend)
+{
+    API_BEGIN
+    dom_require(ctx);
+    auto &d = ctx->dom;
+    hipStream_t st = ctx->stream;
+    d.n_old = ctx->n;
+    d.n_arr = 0;
+    d.n_xh = 0;
+    HIPCHK(hipMemsetAsync(d.counters.p, 0, 8 * sizeof(int32_t), st));
+    int cap_rec = (int)(d.sbuf[0].n / MD_MIG_REC);
+    double inv_w = (double)d.nranks / ctx->L[0];
+    DevState s = ctx->dev(ctx->cur);
+    if (d.n_old > 0) {
+        if (ctx->dim == 3)
+            k_dom_classify<3><<<nblocks(d.n_old), MD_BLOCK, 0, st>>>((int)d.n_old, s, ctx->grid, d.xlo, d.xhi, inv_w,
+                                                                     d.rank, d.nranks, d.alive.p, d.sbuf[0].p,
+                                                                     d.sbuf[1].p, cap_rec, (DomCounters *)d.counters.p);
+        else
+            k_dom_classify<2><<<nblocks(d.n_old), MD_BLOCK, 0, st>>>((int)d.n_old, s, ctx->grid, d.xlo, d.xhi, inv_w,
+                                                                     d.rank, d.nranks, d.alive.p, d.sbuf[0].p,
+                                                                     d.sbuf[1].p, cap_rec, (DomCounters *)d.counters.p);
+        HIPCHK(hipGetLastError());
+    }
+    DomCounters h = dom_read_counters(ctx);
+    d.nsend_mig[0] = h.mig[0];
+    d.nsend_mig[1] = h.mig[1];
+    if (nsend) {
+        nsend[0] = h.mig[0];
+        nsend[1] = h.mig[1];
+    }
+    ctx->list_valid = false;
+    API_END
+}
+
+// raw access to the exchange buffers: side 0 = left neighbour, 1 = right neighbour.
+int md_dom_get_sendbuf(md_ctx *ctx, int side, int64_t ndoubles, void *dst, int dst_is_device)
+{
+    API_BEGIN
+    dom_require(ctx);
+    if (side < 0 || side > 1 || ndoubles < 0 || (size_t)ndoubles > ctx->dom.sbuf[side].n)
+        throw HipError("md_dom_get_sendbuf: bad arguments");
+    if (ndoubles > 0) {
+        HIPCHK(hipMemcpyAsync(dst, ctx->dom.sbuf[side].p, ndoubles * sizeof(double),
+                              dst_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    API_END
+}
+
+int md_dom_put_recvbuf(md_ctx *ctx, int side, int64_t ndoubles, const void *src, int src_is_device)
+{
+    API_BEGIN
+    dom_require(ctx);
+    if (side < 0 || side > 1 || ndoubles < 0 || (size_t)ndoubles > ctx->dom.rbuf[side].n)
+        throw HipError("md_dom_put_recvbuf: message larger than the receive buffer (raise n_cap)");
+    if (ndoubles > 0) {
+        HIPCHK(hipMemcpyAsync(ctx->dom.rbuf[side].p, src, ndoubles * sizeof(double),
+                              src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    API_END
+}
+
+// step 2: adopt the arrivals (nrecv[side] records in the receive buffers)
+int md_dom_migrate_unpack(md_ctx *ctx, const int64_t *nrecv)
+{
+    API_BEGIN
+    dom_require(ctx);
+    auto &d = ctx->dom;
+    hipStream_t st = ctx->stream;
+    int64_t tot = nrecv[0] + nrecv[1];
+    if (d.n_old + tot > ctx->ncap) throw HipError("owned-particle capacity exceeded on migration (raise n_cap)");
+    ensure_capacity(ctx, d.n_old + tot + 1);
+    if ((size_t)(d.n_old + tot + 2) > d.alive.n) throw HipError("source table exceeded (raise n_cap)");
+    DevState s = ctx->dev(ctx->cur);
+    int64_t base = d.n_old;
+    for (int sd = 0; sd < 2; ++sd) {
+        if (nrecv[sd] > 0) {
+            if (ctx->dim == 3)
+                k_dom_unpack_mig<3><<<nblocks(nrecv[sd]), MD_BLOCK, 0, st>>>((int)nrecv[sd], (int)base, d.rbuf[sd].p, s,
+                                                                            d.alive.p);
+            else
+                k_dom_unpack_mig<2><<<nblocks(nrecv[sd]), MD_BLOCK, 0, st>>>((int)nrecv[sd], (int)base, d.rbuf[sd].p, s,
+                                                                            d.alive.p);
+            base += nrecv[sd];
+        }
+    }
+    HIPCHK(hipGetLastError());
+    d.n_arr = tot;
+    ctx->src_count = d.n_old + tot;
+    HIPCHK(hipStreamSynchronize(st));
+    API_END
+}
+
+// step 3: select and pack the particles within rc+skin of the slab faces (MD_HALO_REC doubles each)
+int md_dom_halo_pack(md_ctx *ctx, int64_t *nsend)
+{
+    API_BEGIN
+    dom_require(ctx);
+    auto &d = ctx->dom;
+    hipStream_t st = ctx->stream;
+    int n_own_src = (int)(d.n_old + d.n_arr);
+    int cap_rec = (int)std::min<size_t>(d.sbuf[0].n / MD_HALO_REC, d.hs_src[0].n);
+    HIPCHK(hipMemsetAsync(d.counters.p, 0, 8 * sizeof(int32_t), st));
+    double shift_l = (d.rank == 0) ? ctx->L[0] : 0.0;
+    double shift_r = (d.rank == d.nranks - 1) ? -ctx->L[0] : 0.0;
+    DevState s = ctx->dev(ctx->cur);
+    if (n_own_src > 0)
+        k_dom_select_halo<<<nblocks(n_own_src), MD_BLOCK, 0, st>>>(n_own_src, s, d.xlo, d.xhi, ctx->rl, shift_l, shift_r,
+                                                                   d.alive.p, d.sbuf[0].p, d.sbuf[1].p, d.hs_src[0].p,
+                                                                   d.hs_src[1].p, cap_rec, (DomCounters *)d.counters.p);
+    HIPCHK(hipGetLastError());
+    DomCounters h = dom_read_counters(ctx);
+    d.nsend_halo[0] = h.halo[0];
+    d.nsend_halo[1] = h.halo[1];
+    if (nsend) {
+        nsend[0] = h.halo[0];
+        nsend[1] = h.halo[1];
+    }
+    API_END
+}
+
+// step 4: adopt the neighbours' halo records as x-halo sources
+int md_dom_halo_unpack(md_ctx *ctx, const int64_t *nrecv)
+{
+    API_BEGIN
+    dom_require(ctx);
+    auto &d = ctx->dom;
+    hipStream_t st = ctx->stream;
+    int64_t n_own_src = d.n_old + d.n_arr;
+    int64_t tot = nrecv[0] + nrecv[1];
+    if ((size_t)tot > d.xh_slot.n) throw HipError("x-halo capacity exceeded (raise n_cap)");
+    ctx->src_count = n_own_src;
+    ensure_capacity(ctx, n_own_src + tot + 1);
+    if ((size_t)(n_own_src + tot + 2) > d.alive.n) throw HipError("source table exceeded (raise n_cap)");
+    DevState s = ctx->dev(ctx->cur);
+    int64_t base = n_own_src;
+    for (int sd = 0; sd < 2; ++sd) {
+        if (nrecv[sd] > 0) {
+            k_dom_unpack_halo<<<nblocks(nrecv[sd]), MD_BLOCK, 0, st>>>((int)nrecv[sd], (int)base, d.rbuf[sd].p, s,
+                                                                      d.alive.p);
+            base += nrecv[sd];
+        }
+        d.nrecv_halo[sd] = nrecv[sd];
+    }
+    HIPCHK(hipGetLastError());
+    d.n_xh = tot;
+    ctx->src_count = n_own_src + tot;
+    HIPCHK(hipStreamSynchronize(st));
+    API_END
+}
+
+// step 5: sort, ghosts, neighbour rows; fix the per-step halo slot tables
+int md_dom_build(md_ctx *ctx)
+{
+    API_BEGIN
+    dom_require(ctx);
+    auto &d = ctx->dom;
+    hipStream_t st = ctx->stream;
+    int64_t n_own_src = d.n_old + d.n_arr;
+    rebuild(ctx);
+    for (int sd = 0; sd < 2; ++sd)
+        if (d.nsend_halo[sd] > 0)
+            k_dom_map_slots<<<nblocks(d.nsend_halo[sd]), MD_BLOCK, 0, st>>>((int)d.nsend_halo[sd], d.hs_src[sd].p, 0,
+                                                                           ctx->newslot.p, d.send_slot[sd].p);
+    if (d.n_xh > 0)
+        k_dom_map_slots<<<nblocks(d.n_xh), MD_BLOCK, 0, st>>>((int)d.n_xh, nullptr, (int)n_own_src, ctx->newslot.p,
+                                                              d.xh_slot.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    d.n_old = ctx->n;
+    d.n_arr = 0;
+    API_END
+}
+
+// first half of a step: (pending rescale,) half-kick, drift, displacement check, and the halo
+// coordinates packed for the neighbours (3 doubles per record, nsend_halo[side] records).
+int md_dom_step_begin(md_ctx *ctx, double dt, int *violated)
+{
+    API_BEGIN
+    dom_require(ctx);
+    if (!ctx->list_valid) throw HipError("md_dom_step_begin: no valid neighbour list (run the build sequence first)");
+    auto &d = ctx->dom;
+    hipStream_t st = ctx->stream;
+    k_reset_viol<<<1, 1, 0, st>>>(ctx->scal.p);
+    double thr2 = (0.5 * ctx->skin) * (0.5 * ctx->skin);
+    if (ctx->n > 0) launch_kickdrift(ctx, true, dt, thr2, 0);
+    k_set_scale<<<1, 1, 0, st>>>(ctx->scal.p, 1.0);
+    DevState s = ctx->dev(ctx->cur);
+    double shift_l = (d.rank == 0) ? ctx->L[0] : 0.0;
+    double shift_r = (d.rank == d.nranks - 1) ? -ctx->L[0] : 0.0;
+    for (int sd = 0; sd < 2; ++sd)
+        if (d.nsend_halo[sd] > 0)
+            k_dom_pack_pos<<<nblocks(d.nsend_halo[sd]), MD_BLOCK, 0, st>>>((int)d.nsend_halo[sd], d.send_slot[sd].p,
+                                                                          s.pos, sd ? shift_r : shift_l, d.sbuf[sd].p);
+    HIPCHK(hipGetLastError());
+    Scalars h = read_scalars(ctx);
+    if (violated) *violated = (h.first_viol != MD_NO_VIOLATION) ? 1 : 0;
+    API_END
+}
+
+// second half: adopt the neighbours' halo coordinates, refresh the self-image ghosts, forces,
+// second half-kick.  uwk receives this rank's share {U, W, K}.
+int md_dom_step_end(md_ctx *ctx, double dt, int want_uw, double *uwk)
+{
+    API_BEGIN
+    dom_require(ctx);
+    auto &d = ctx->dom;
+    hipStream_t st = ctx->stream;
+    DevState s = ctx->dev(ctx->cur);
+    int64_t off = 0;
+    for (int sd = 0; sd < 2; ++sd) {
+        if (d.nrecv_halo[sd] > 0)
+            k_dom_unpack_pos<<<nblocks(d.nrecv_halo[sd]), MD_BLOCK, 0, st>>>((int)d.nrecv_halo[sd], d.xh_slot.p + off,
+                                                                            d.rbuf[sd].p, s.pos);
+        off += d.nrecv_halo[sd];
+    }
+    launch_ghost_update(ctx, -1);
+    if (ctx->n > 0) {
+        launch_force(ctx, want_uw != 0, true, dt, -1);
+        launch_finalize(ctx, want_uw != 0, false, 1.0, 0.0, -1);
+    }
+    HIPCHK(hipGetLastError());
+    Scalars h = read_scalars(ctx);
+    if (uwk) {
+        uwk[0] = (ctx->n > 0 && want_uw) ? h.U : 0.0;
+        uwk[1] = (ctx->n > 0 && want_uw) ? h.W : 0.0;
+        uwk[2] = (ctx->n > 0) ? h.K : 0.0;
+    }
+    ctx->st_steps += 1;
+    API_END
+}
+
+// the force half alone (after a build triggered by a displacement violation, and for
+// md_compute_forces-like calls): neighbours' coordinates are the ones delivered at the build.
+int md_dom_forces(md_ctx *ctx, double dt, int kick, int want_uw, double *uwk)
+{
+    API_BEGIN
+    dom_require(ctx);
+    if (!ctx->list_valid) throw HipError("md_dom_forces: no valid neighbour list");
+    if (ctx->n > 0) {
+        launch_force(ctx, want_uw != 0, kick != 0, dt, -1);
+        launch_finalize(ctx, want_uw != 0, false, 1.0, 0.0, -1);
+    }
+    HIPCHK(hipGetLastError());
+    Scalars h = read_scalars(ctx);
+    if (uwk) {
+        uwk[0] = (ctx->n > 0 && want_uw) ? h.U : 0.0;
+        uwk[1] = (ctx->n > 0 && want_uw) ? h.W : 0.0;
+        uwk[2] = (ctx->n > 0 && kick) ? h.K : 0.0;
+    }
+    API_END
+}
+
+// the Bussi scale computed by the caller from the all-reduced kinetic energy; applied in front of
+// the next half-kick (src/thermostat.jl:43-45)
+int md_dom_set_scale(md_ctx *ctx, double scale)
+{
+    API_BEGIN
+    dom_require(ctx);
+    k_set_scale<<<1, 1, 0, ctx->stream>>>(ctx->scal.p, scale);
+    HIPCHK(hipGetLastError());
+    API_END
+}
+
+int md_dom_counts(md_ctx *ctx, int64_t *out /* n_own, nsend_halo L/R, nrecv_halo L/R, n_ghost */)
+{
+    API_BEGIN
+    dom_require(ctx);
+    out[0] = ctx->n;
+    out[1] = ctx->dom.nsend_halo[0];
+    out[2] = ctx->dom.nsend_halo[1];
+    out[3] = ctx->dom.nrecv_halo[0];
+    out[4] = ctx->dom.nrecv_halo[1];
+    out[5] = ctx->nghost;
     API_END
 }
 

@@ -1,0 +1,327 @@
+"""1-D slab decomposition over the GPUs of one node: one process per GPU, one libmdhip handle per
+process (md_create_domain), neighbour exchange through torch.distributed -- backend "nccl" is RCCL
+over xGMI on a multi-GPU MI355X node; "gloo" (host staging) is used by the tests that run several
+ranks on one GPU or on CPUs.
+
+New relative to the reference, which is single-process.  The physics is the
+single-GPU path's: each rank runs the same kernels on the particles of its slab; the x-direction
+ghost copies are fed by the two neighbour ranks instead of by periodic self-images.
+
+  list build : migrate_pack -> exchange -> migrate_unpack -> halo_pack -> exchange -> halo_unpack -> build
+  step       : step_begin (kick+drift, pack) -> all-reduce(violation) -> exchange -> step_end (forces, kick)
+  reductions : U, W, K are all-reduced (every step for NVT: Bussi needs the global kinetic energy)
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import MdhipError
+from .thermostat import bussi_scale
+
+MIG_REC, HALO_REC, POS_REC = 14, 5, 3
+
+
+# ---------------------------------------------------------------------------------------------
+# host-side geometry helpers (pure numpy: covered by the CPU tests)
+# ---------------------------------------------------------------------------------------------
+def slab_bounds(L, nranks, rank):
+    """[x_lo, x_hi) of a rank's slab -- the same arithmetic as md_create_domain."""
+    lo = L * rank / nranks
+    hi = L if rank == nranks - 1 else L * (rank + 1) / nranks
+    return lo, hi
+
+
+def owner_of(x, L, nranks):
+    """Owning rank of x-coordinates in [0, L] (x == L belongs to the last slab)."""
+    o = np.floor(np.asarray(x) * (nranks / L)).astype(np.int64)
+    return np.clip(o, 0, nranks - 1)
+
+
+def neighbours(rank, nranks):
+    return (rank - 1) % nranks, (rank + 1) % nranks
+
+
+def halo_selection(x, lo, hi, rl):
+    """Boolean masks (to_left, to_right) of the particles of a slab a neighbour needs."""
+    x = np.asarray(x)
+    return x < lo + rl, x >= hi - rl
+
+
+# ---------------------------------------------------------------------------------------------
+# transport
+# ---------------------------------------------------------------------------------------------
+class Exchanger:
+    """Ring exchange with the two neighbours.  Buffers are torch tensors on the GPU (nccl) or on
+    the host (gloo)."""
+
+    def __init__(self, device_index=0, group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group = torch, dist, group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.left, self.right = neighbours(self.rank, self.world)
+        self.on_device = dist.get_backend(group) == "nccl"
+        self.device = torch.device("cuda", device_index) if self.on_device else torch.device("cpu")
+        self._bufs = {}
+
+    def buffer(self, name, n):
+        b = self._bufs.get(name)
+        if b is None or b.numel() < n:
+            b = self.torch.empty(max(int(n * 1.25), 1024), dtype=self.torch.float64, device=self.device)
+            self._bufs[name] = b
+        return b
+
+    def all_counts(self, nsend):
+        """nsend = (to_left, to_right) -> (from_left, from_right)."""
+        t = self.torch.tensor([int(nsend[0]), int(nsend[1])], dtype=self.torch.int64, device=self.device)
+        out = [self.torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t, group=self.group)
+        return int(out[self.left][1].item()), int(out[self.right][0].item())
+
+    def sendrecv(self, send_left, send_right, recv_left, recv_right):
+        """Post both sends and both receives.  For two ranks both neighbours are the same peer, so
+        the receive order mirrors the peer's send order (its left-bound message is my from-right)."""
+        dist = self.dist
+        ops = []
+        if send_left.numel():
+            ops.append(dist.P2POp(dist.isend, send_left, self.left, self.group, tag=1))
+        if send_right.numel():
+            ops.append(dist.P2POp(dist.isend, send_right, self.right, self.group, tag=2))
+        if recv_right.numel():
+            ops.append(dist.P2POp(dist.irecv, recv_right, self.right, self.group, tag=1))
+        if recv_left.numel():
+            ops.append(dist.P2POp(dist.irecv, recv_left, self.left, self.group, tag=2))
+        if ops:
+            for r in dist.batch_isend_irecv(ops):
+                r.wait()
+            if self.on_device:
+                self.torch.cuda.current_stream().synchronize()
+
+    def allreduce(self, values, op="sum"):
+        t = self.torch.tensor(values, dtype=self.torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM if op == "sum" else self.dist.ReduceOp.MAX,
+                             group=self.group)
+        return t.tolist()
+
+
+# ---------------------------------------------------------------------------------------------
+# one rank's handle
+# ---------------------------------------------------------------------------------------------
+class DomainDevice:
+    """A slab handle (md_create_domain) plus the exchange choreography."""
+
+    def __init__(self, dim, n_global, box, list_cutoff, exchanger, device_id=0, cap_factor=1.3, n_cap=None):
+        self._L = _lib.load()
+        self.ex = exchanger
+        self.dim, self.n_global = int(dim), int(n_global)
+        self.rank, self.nranks = exchanger.rank, exchanger.world
+        if self.nranks < 2:
+            raise ValueError("DomainDevice needs at least 2 ranks (use MDDevice on one GPU)")
+        box = np.asarray(box, dtype=np.float64)
+        if box.ndim == 0:
+            box = np.eye(self.dim) * float(box)
+        elif box.ndim == 1:
+            box = np.diag(box)
+        self.unitcell = np.ascontiguousarray(box[: self.dim, : self.dim])
+        self.Lx = float(self.unitcell[0, 0])
+        self.xlo, self.xhi = slab_bounds(self.Lx, self.nranks, self.rank)
+        if n_cap is None:
+            n_cap = int(cap_factor * self.n_global / self.nranks) + 4096
+        self.n_cap = int(n_cap)
+        cm = np.ascontiguousarray(self.unitcell.T)
+        h = C.c_void_p()
+        rc = self._L.md_create_domain(self.dim, self.n_global, self.n_cap, cm.ctypes.data_as(C.POINTER(C.c_double)),
+                                      float(list_cutoff), int(device_id), self.rank, self.nranks, C.byref(h))
+        if rc != 0:
+            raise MdhipError(self._L.md_last_error(None).decode())
+        self._h = h
+        self.steps_since_build = 0
+        self.target_interval = 8
+        self.builds = 0
+        self.violations = 0
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise MdhipError(self._L.md_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.md_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- configuration / state ----------------------------------------------------------------
+    def set_potential(self, kind, params):
+        p = np.ascontiguousarray(params, dtype=np.float64)
+        self._chk(self._L.md_set_potential(self._h, int(kind), p.ctypes.data_as(C.POINTER(C.c_double)), int(p.size)))
+
+    def set_skin(self, skin):
+        self._chk(self._L.md_set_skin(self._h, float(skin)))
+
+    def upload_global(self, x, v, f, images, diameters):
+        """Every rank holds the global arrays (row i = particle i) and keeps its slab's share."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        mine = np.nonzero(owner_of(x[:, 0], self.Lx, self.nranks) == self.rank)[0]
+        ids = mine.astype(np.int32)
+        diam = np.ascontiguousarray(diameters, dtype=np.float64)
+        self._chk(self._L.md_dom_set_uniform(self._h, 1 if np.all(diam == diam[0]) else 0, float(diam[0])))
+        self.upload_local(ids, x[mine], None if v is None else np.asarray(v)[mine],
+                          None if f is None else np.asarray(f)[mine],
+                          None if images is None else np.asarray(images)[mine], diam[mine])
+
+    def upload_local(self, ids, x, v, f, images, diameters):
+        dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        n = ids.size
+
+        def d(a):
+            return None if a is None else np.ascontiguousarray(a, dtype=np.float64).ctypes.data_as(dp)
+
+        keep = [np.ascontiguousarray(a, dtype=np.float64) if a is not None else None for a in (x, v, f, diameters)]
+        im = None if images is None else np.ascontiguousarray(images, dtype=np.int32)
+        self._chk(self._L.md_dom_upload(self._h, n, ids.ctypes.data_as(ip),
+                                        *(None if a is None else a.ctypes.data_as(dp) for a in keep[:3]),
+                                        None if im is None else im.ctypes.data_as(ip),
+                                        None if keep[3] is None else keep[3].ctypes.data_as(dp)))
+
+    def download_local(self):
+        cap = self.n_cap
+        ids = np.empty(cap, dtype=np.int32)
+        x = np.empty((cap, self.dim))
+        v = np.empty((cap, self.dim))
+        f = np.empty((cap, self.dim))
+        im = np.empty((cap, self.dim), dtype=np.int32)
+        n = C.c_int64()
+        dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+        self._chk(self._L.md_dom_download(self._h, cap, C.byref(n), ids.ctypes.data_as(ip), x.ctypes.data_as(dp),
+                                          v.ctypes.data_as(dp), f.ctypes.data_as(dp), im.ctypes.data_as(ip)))
+        n = n.value
+        return ids[:n], x[:n], v[:n], f[:n], im[:n]
+
+    def gather_global(self):
+        """All ranks' particles assembled in id order on every rank (test / output helper)."""
+        ids, x, v, f, im = self.download_local()
+        objs = [None] * self.nranks
+        self.ex.dist.all_gather_object(objs, (ids, x, v, f, im), group=self.ex.group)
+        n = self.n_global
+        X, V, F = np.empty((n, self.dim)), np.empty((n, self.dim)), np.empty((n, self.dim))
+        IM = np.empty((n, self.dim), dtype=np.int32)
+        seen = np.zeros(n, dtype=np.int64)
+        for (i_, x_, v_, f_, m_) in objs:
+            X[i_], V[i_], F[i_], IM[i_] = x_, v_, f_, m_
+            seen[i_] += 1
+        if not np.all(seen == 1):
+            raise MdhipError("particle ownership is not a partition")
+        return X, V, F, IM
+
+    def counts(self):
+        out = (C.c_int64 * 6)()
+        self._chk(self._L.md_dom_counts(self._h, out))
+        return dict(n_own=out[0], nsend_halo=(out[1], out[2]), nrecv_halo=(out[3], out[4]), n_ghost=out[5])
+
+    # -- exchange plumbing ----------------------------------------------------------------------
+    def _exchange(self, nsend, rec):
+        """Move nsend[side] records of `rec` doubles to the neighbours; returns nrecv (from_left, from_right)."""
+        ex = self.ex
+        nrecv = ex.all_counts(nsend)
+        dev = 1 if ex.on_device else 0
+        sl = ex.buffer("sl", nsend[0] * rec)[: nsend[0] * rec]
+        sr = ex.buffer("sr", nsend[1] * rec)[: nsend[1] * rec]
+        rl = ex.buffer("rl", nrecv[0] * rec)[: nrecv[0] * rec]
+        rr = ex.buffer("rr", nrecv[1] * rec)[: nrecv[1] * rec]
+        self._chk(self._L.md_dom_get_sendbuf(self._h, 0, nsend[0] * rec, sl.data_ptr(), dev))
+        self._chk(self._L.md_dom_get_sendbuf(self._h, 1, nsend[1] * rec, sr.data_ptr(), dev))
+        ex.sendrecv(sl, sr, rl, rr)
+        self._chk(self._L.md_dom_put_recvbuf(self._h, 0, nrecv[0] * rec, rl.data_ptr(), dev))
+        self._chk(self._L.md_dom_put_recvbuf(self._h, 1, nrecv[1] * rec, rr.data_ptr(), dev))
+        return nrecv
+
+    def _exchange_fixed(self, nsend, nrecv, rec):
+        """Per-step exchange: the counts were fixed at the build."""
+        ex = self.ex
+        dev = 1 if ex.on_device else 0
+        sl = ex.buffer("sl", nsend[0] * rec)[: nsend[0] * rec]
+        sr = ex.buffer("sr", nsend[1] * rec)[: nsend[1] * rec]
+        rl = ex.buffer("rl", nrecv[0] * rec)[: nrecv[0] * rec]
+        rr = ex.buffer("rr", nrecv[1] * rec)[: nrecv[1] * rec]
+        self._chk(self._L.md_dom_get_sendbuf(self._h, 0, nsend[0] * rec, sl.data_ptr(), dev))
+        self._chk(self._L.md_dom_get_sendbuf(self._h, 1, nsend[1] * rec, sr.data_ptr(), dev))
+        ex.sendrecv(sl, sr, rl, rr)
+        self._chk(self._L.md_dom_put_recvbuf(self._h, 0, nrecv[0] * rec, rl.data_ptr(), dev))
+        self._chk(self._L.md_dom_put_recvbuf(self._h, 1, nrecv[1] * rec, rr.data_ptr(), dev))
+
+    # -- list build -----------------------------------------------------------------------------
+    def build(self):
+        ns = (C.c_int64 * 2)()
+        self._chk(self._L.md_dom_migrate_pack(self._h, ns))
+        nrecv = self._exchange((ns[0], ns[1]), MIG_REC)
+        self._chk(self._L.md_dom_migrate_unpack(self._h, (C.c_int64 * 2)(*nrecv)))
+        self._chk(self._L.md_dom_halo_pack(self._h, ns))
+        self._nsend_halo = (ns[0], ns[1])
+        self._nrecv_halo = self._exchange(self._nsend_halo, HALO_REC)
+        self._chk(self._L.md_dom_halo_unpack(self._h, (C.c_int64 * 2)(*self._nrecv_halo)))
+        self._chk(self._L.md_dom_build(self._h))
+        self.steps_since_build = 0
+        self.builds += 1
+
+    # -- forces / steps -------------------------------------------------------------------------
+    def compute_forces(self):
+        """Global U, W at the current positions (reset_output! + map_pairwise!)."""
+        self.build()
+        uwk = (C.c_double * 3)()
+        self._chk(self._L.md_dom_forces(self._h, 0.0, 0, 1, uwk))
+        U, W = self.ex.allreduce([uwk[0], uwk[1]])
+        return U, W
+
+    def run(self, nsteps, dt, ensemble=_lib.MD_NVE, tau=0.0, nf=None, ktemp=None, r1=None, r2=None):
+        """The step loop of run_simulation! across the slabs; returns global (U, W, K) of the last step.
+        r1, r2, ktemp must be identical on every rank (draw them from one seeded stream)."""
+        nf = float(self.dim * (self.n_global - 1.0)) if nf is None else float(nf)
+        nvt = ensemble == _lib.MD_NVT
+        uwk = (C.c_double * 3)()
+        viol = C.c_int()
+        U = W = K = float("nan")
+        scale = 1.0
+        if self.builds == 0:
+            self.build()
+        for s in range(nsteps):
+            last = s == nsteps - 1
+            self._chk(self._L.md_dom_step_begin(self._h, float(dt), C.byref(viol)))
+            any_viol = self.ex.allreduce([float(viol.value)], op="max")[0] > 0.0
+            if any_viol:
+                # some particle somewhere moved skin/2: every rank rebuilds at the drifted positions
+                self.violations += 1
+                observed = self.steps_since_build + 1
+                self.target_interval = max(2, (observed * 4) // 5)
+                self.build()
+                self._chk(self._L.md_dom_forces(self._h, float(dt), 1, 1 if last else 0, uwk))
+            else:
+                self._exchange_fixed(self._nsend_halo, self._nrecv_halo, POS_REC)
+                self._chk(self._L.md_dom_step_end(self._h, float(dt), 1 if last else 0, uwk))
+                self.steps_since_build += 1
+            if nvt or last:
+                U, W, K = self.ex.allreduce([uwk[0], uwk[1], uwk[2]])
+            if nvt:
+                scale = float(bussi_scale(K, ktemp[s], nf, dt, tau, r1[s], r2[s]))
+                K = K * scale * scale
+                if last:
+                    self._chk(self._L.md_scale_velocities(self._h, scale))   # leave a downloadable state
+                else:
+                    self._chk(self._L.md_dom_set_scale(self._h, scale))
+            if not last and not any_viol and self.steps_since_build >= self.target_interval:
+                self.build()
+                self.target_interval += 1
+        return U, W, K

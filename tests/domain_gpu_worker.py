@@ -1,0 +1,71 @@
+"""Worker for tests/test_domain_gpu.py: launched by torch.distributed.run with N ranks that all use GPU 0
+(gloo transport, host staging).  Compares the slab-decomposed run with a single-handle run of the same
+system (rank 0) and, for forces, with the CPU oracle."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch.distributed as dist
+    from moleculardynamics.jl_amd import MDDevice, _lib
+    from moleculardynamics.jl_amd.domain import DomainDevice, Exchanger
+    from tests.util import lj_system
+
+    dist.init_process_group(backend="gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    n = int(os.environ.get("DOM_N", "8000"))
+    kT = float(os.environ.get("DOM_KT", "2.0"))
+    nsteps = int(os.environ.get("DOM_STEPS", "60"))
+    nvt = os.environ.get("DOM_NVT", "0") == "1"
+    s = lj_system(n, kT=kT, permute=777)     # shuffled ids: ownership is by position, not by index
+    LJ = [1.0, 1.0, 2.5]
+    ex = Exchanger(device_index=0)
+    rng = np.random.default_rng(99)
+    nf = 3 * (n - 1.0)
+    r1 = rng.standard_normal(nsteps)
+    r2 = 2.0 * rng.gamma((nf - 1) / 2, size=nsteps)
+    kt = np.full(nsteps, kT)
+    ens = _lib.MD_NVT if nvt else _lib.MD_NVE
+    with DomainDevice(3, n, s["box"], 2.5, ex, device_id=0) as d:
+        d.set_potential(0, LJ)
+        d.upload_global(s["x"], s["v"], s["f"], s["img"], s["diam"])
+        U, W = d.compute_forces()
+        X0, V0, F0, I0 = d.gather_global()
+        d.upload_global(s["x"], s["v"], s["f"], s["img"], s["diam"])
+        d.builds = 0
+        Ue, We, Ke = d.run(nsteps, 0.002, ens, 0.1, nf, kt, r1, r2)
+        X, V, F, IM = d.gather_global()
+        stats = (d.builds, d.violations, d.counts())
+    ok = True
+    if rank == 0:
+        from oracle import oracle as orc
+        pot = orc.make_pot(orc.POT_LJ, LJ)
+        f_ref, u_ref, w_ref, _ = orc.forces_cells(s["x"], s["box"], 2.5, pot, s["diam"], nthreads=2)
+        scale = max(1.0, np.abs(f_ref).max())
+        e_f = np.abs(F0 - f_ref).max() / scale
+        print(f"[dom] world={world} forces vs oracle: dF={e_f:.2e} dU={abs(U-u_ref)/abs(u_ref):.2e} dW={abs(W-w_ref)/abs(w_ref):.2e}")
+        ok &= e_f <= 1e-11 and abs(U - u_ref) <= 1e-12 * abs(u_ref) and abs(W - w_ref) <= 1e-12 * abs(w_ref)
+        with MDDevice(3, n, s["box"], 2.5, device_id=0) as g:
+            g.set_potential(0, LJ)
+            g.upload(s["x"], s["v"], s["f"], s["img"], s["diam"])
+            U1, W1, K1 = g.run(nsteps, 0.002, ens, 0.1, nf, kt, r1, r2)
+            x1, v1, f1, im1 = g.download()
+        dx, dv = np.abs(X - x1).max(), np.abs(V - v1).max()
+        print(f"[dom] {nsteps} steps {'NVT' if nvt else 'NVE'}: dx={dx:.2e} dv={dv:.2e} dK={abs(Ke-K1)/K1:.2e} "
+              f"dU={abs(Ue-U1)/abs(U1):.2e} images_equal={np.array_equal(IM, im1)} builds={stats[0]} viol={stats[1]} {stats[2]}")
+        ok &= dx <= 1e-8 and dv <= 1e-8 and abs(Ke - K1) <= 1e-9 * K1 and abs(Ue - U1) <= 1e-9 * abs(U1)
+        ok &= np.array_equal(IM, im1)
+        ok &= stats[0] >= 2          # at least one rebuild with migration happened
+    flag = [ok]
+    dist.broadcast_object_list(flag, src=0)
+    dist.destroy_process_group()
+    sys.exit(0 if flag[0] else 1)
+
+
+if __name__ == "__main__":
+    main()
