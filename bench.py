@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--n", type=int, default=1048576, help="particles per GPU")
+    ap.add_argument("--particles", dest="n", type=int, default=1048576, help="particles per GPU")
     ap.add_argument("--ensemble", choices=["nvt", "nve"], default="nvt")
     ap.add_argument("--skin", type=float, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -102,8 +102,14 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("MDHIP_BENCH_BACKEND", "nccl")   # "gloo": functional runs of several ranks on one GPU
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group(backend=backend)
     else:
         torch.cuda.set_device(local_rank)
 
@@ -111,24 +117,53 @@ def main():
     from moleculardynamics.jl_amd.thermostat import draw_bussi
 
     dt, tau = 0.001, 0.1
-    inp = make_inputs(a.n, seed_shift=rank)
-    nf = 3.0 * (a.n - 1.0)
     nvt = a.ensemble == "nvt"
-    dev = MDDevice(3, a.n, inp["box"], 2.5, device_id=local_rank)
-    dev.set_potential(_lib.MD_POT_LJ, [1.0, 1.0, 2.5])
-    if a.skin is not None:
-        dev.set_skin(a.skin)
-    dev.upload(inp["x"], inp["v"], inp["f"], inp["img"], inp["diam"])
-    rng = np.random.default_rng(4242 + rank)
+    inp = make_inputs(a.n, seed_shift=rank)
+    if world == 1:
+        nf = 3.0 * (a.n - 1.0)
+        dev = MDDevice(3, a.n, inp["box"], 2.5, device_id=local_rank)
+        dev.set_potential(_lib.MD_POT_LJ, [1.0, 1.0, 2.5])
+        if a.skin is not None:
+            dev.set_skin(a.skin)
+        dev.upload(inp["x"], inp["v"], inp["f"], inp["img"], inp["diam"])
+        rng = np.random.default_rng(4242)
 
-    def run(nsteps, thermo=False):
-        if nsteps <= 0:
-            return None
-        if nvt:
-            kt = np.full(nsteps, inp["kT"])
-            r1, r2 = draw_bussi(nf, rng, nsteps)
-            return dev.run(nsteps, dt, _lib.MD_NVT, tau, nf, kt, r1, r2, thermo=thermo)
-        return dev.run(nsteps, dt, _lib.MD_NVE, thermo=thermo)
+        def run(nsteps, thermo=False):
+            if nsteps <= 0:
+                return None
+            if nvt:
+                kt = np.full(nsteps, inp["kT"])
+                r1, r2 = draw_bussi(nf, rng, nsteps)
+                return dev.run(nsteps, dt, _lib.MD_NVT, tau, nf, kt, r1, r2, thermo=thermo)
+            return dev.run(nsteps, dt, _lib.MD_NVE, thermo=thermo)
+    else:
+        # weak scaling: every rank owns one cube of a.n particles; the global box is `world` cubes long in
+        # x, cut into slabs (1-D spatial decomposition), halo coordinates exchanged every step
+        from moleculardynamics.jl_amd.domain import DomainDevice, Exchanger
+        ex = Exchanger(device_index=local_rank)
+        L1 = float(inp["box"][0])
+        gbox = np.array([world * L1, L1, L1])
+        n_global = a.n * world
+        nf = 3.0 * (n_global - 1.0)
+        dev = DomainDevice(3, n_global, gbox, 2.5, ex, device_id=local_rank, n_cap=int(1.3 * a.n) + 8192)
+        dev.set_potential(_lib.MD_POT_LJ, [1.0, 1.0, 2.5])
+        if a.skin is not None:
+            dev.set_skin(a.skin)
+        xg = inp["x"].copy()
+        xg[:, 0] += rank * L1
+        ids = (rank * a.n + np.arange(a.n)).astype(np.int32)
+        dev.set_uniform(True, 1.0)
+        dev.upload_local(ids, xg, inp["v"], inp["f"], inp["img"], inp["diam"])
+        rng = np.random.default_rng(4242)      # the same stream on every rank: identical thermostat noise
+
+        def run(nsteps, thermo=False):
+            if nsteps <= 0:
+                return None
+            if nvt:
+                kt = np.full(nsteps, inp["kT"])
+                r1, r2 = draw_bussi(nf, rng, nsteps)
+                return dev.run(nsteps, dt, _lib.MD_NVT, tau, nf, kt, r1, r2)
+            return dev.run(nsteps, dt, _lib.MD_NVE)
 
     def barrier():
         if dist is not None:
@@ -154,6 +189,7 @@ def main():
 
     total_particles = a.n * world
     value = total_particles * a.steps / el
+    n_for_thermo = total_particles
     launches = max(1, st1["force_launches"])
     kern_ms = st1["force_ms"] / launches
     achieved = (FORCE_KERNEL_BYTES * a.n) / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
@@ -175,9 +211,11 @@ def main():
             "workload": f"BASELINE configs[2]: N={a.n} monodisperse LJ 3D rho=0.897 r_cut=2.5 dt=0.001 "
                         f"{'NVT Bussi tau=0.1 kT=1.4737' if nvt else 'NVE'}, per GPU",
             "particles_per_gpu": a.n,
-            "parallelism": "1 GPU" if world == 1 else f"{world} independent replicas (no data-path collective yet)",
+            "parallelism": "1 GPU" if world == 1 else f"{world}-way 1-D slab decomposition along x, halo exchange every "
+                                                            f"step over torch.distributed ({dist.get_backend()})",
             "skin": a.skin if a.skin is not None else 0.4,
             "rebuilds_in_timed_region": st1["rebuilds"] - st0["rebuilds"],
+            "global_particles": total_particles,
             "avg_list_candidates": st1["avg_neighbors"],
             "tiled_force_kernel": bool(st1["tiled"]),
             "max_tile_halo": st1["max_halo"],
@@ -199,7 +237,7 @@ def main():
             "achieved_GBps": value / world * step_bytes / 1e9,
             "frac_of_8TBps": value / world * step_bytes / 1e9 / HBM_PEAK_GBPS,
         },
-        "thermo_last_step": {"U_per_particle": uwk[0] / a.n, "T": 2.0 * uwk[2] / nf, "W": uwk[1]},
+        "thermo_last_step": {"U_per_particle": uwk[0] / n_for_thermo, "T": 2.0 * uwk[2] / nf, "W": uwk[1]},
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(inp, a.cpu_steps, dt)

@@ -62,8 +62,14 @@ class Exchanger:
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.left, self.right = neighbours(self.rank, self.world)
-        self.on_device = dist.get_backend(group) == "nccl"
+        import os
+        self.p2p_on_device = dist.get_backend(group) == "nccl"
+        # MDHIP_DOM_STAGE=device keeps the exchange buffers on the GPU even under gloo (they are copied
+        # through the host around each send/recv): exercises the device-pointer path of the library
+        # with several ranks on one GPU, where RCCL itself cannot run
+        self.on_device = self.p2p_on_device or os.environ.get("MDHIP_DOM_STAGE", "") == "device"
         self.device = torch.device("cuda", device_index) if self.on_device else torch.device("cpu")
+        self.coll_device = torch.device("cuda", device_index) if self.p2p_on_device else torch.device("cpu")
         self._bufs = {}
 
     def buffer(self, name, n):
@@ -75,7 +81,7 @@ class Exchanger:
 
     def all_counts(self, nsend):
         """nsend = (to_left, to_right) -> (from_left, from_right)."""
-        t = self.torch.tensor([int(nsend[0]), int(nsend[1])], dtype=self.torch.int64, device=self.device)
+        t = self.torch.tensor([int(nsend[0]), int(nsend[1])], dtype=self.torch.int64, device=self.coll_device)
         out = [self.torch.empty_like(t) for _ in range(self.world)]
         self.dist.all_gather(out, t, group=self.group)
         return int(out[self.left][1].item()), int(out[self.right][0].item())
@@ -84,6 +90,11 @@ class Exchanger:
         """Post both sends and both receives.  For two ranks both neighbours are the same peer, so
         the receive order mirrors the peer's send order (its left-bound message is my from-right)."""
         dist = self.dist
+        stage = self.on_device and not self.p2p_on_device
+        if stage:
+            dev_rl, dev_rr = recv_left, recv_right
+            send_left, send_right = send_left.cpu(), send_right.cpu()
+            recv_left, recv_right = self.torch.empty_like(dev_rl, device="cpu"), self.torch.empty_like(dev_rr, device="cpu")
         ops = []
         if send_left.numel():
             ops.append(dist.P2POp(dist.isend, send_left, self.left, self.group, tag=1))
@@ -96,11 +107,15 @@ class Exchanger:
         if ops:
             for r in dist.batch_isend_irecv(ops):
                 r.wait()
-            if self.on_device:
+            if self.p2p_on_device:
                 self.torch.cuda.current_stream().synchronize()
+        if stage:
+            dev_rl.copy_(recv_left)
+            dev_rr.copy_(recv_right)
+            self.torch.cuda.synchronize()
 
     def allreduce(self, values, op="sum"):
-        t = self.torch.tensor(values, dtype=self.torch.float64, device=self.device)
+        t = self.torch.tensor(values, dtype=self.torch.float64, device=self.coll_device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM if op == "sum" else self.dist.ReduceOp.MAX,
                              group=self.group)
         return t.tolist()
@@ -170,6 +185,18 @@ class DomainDevice:
 
     def set_skin(self, skin):
         self._chk(self._L.md_set_skin(self._h, float(skin)))
+
+    def set_uniform(self, uniform, sigma=1.0):
+        """All diameters equal across ALL ranks (selects the uniform-diameter kernels)."""
+        self._chk(self._L.md_dom_set_uniform(self._h, 1 if uniform else 0, float(sigma)))
+
+    def profile(self, enable=True):
+        self._chk(self._L.md_profile(self._h, 1 if enable else 0))
+
+    def stats(self):
+        s = _lib.MdStats()
+        self._chk(self._L.md_get_stats(self._h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in _lib.MdStats._fields_}
 
     def upload_global(self, x, v, f, images, diameters):
         """Every rank holds the global arrays (row i = particle i) and keeps its slab's share."""

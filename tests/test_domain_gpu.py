@@ -23,8 +23,10 @@ def _launch(nproc, env_extra, port):
     assert r.returncode == 0, "slab-decomposed run disagrees with the single-handle run"
 
 
-@pytest.mark.parametrize("nproc,nvt", [(2, 0), (3, 0), (2, 1)])
-def test_slab_decomposition_matches_single_gpu(nproc, nvt):
+@pytest.mark.parametrize("nproc,nvt,stage", [(2, 0, ""), (3, 0, ""), (2, 1, ""), (2, 0, "device")])
+def test_slab_decomposition_matches_single_gpu(nproc, nvt, stage):
     # N=8000 -> L=20.7: 2 slabs of 10.4, 3 slabs of 6.9 (>= 2 cells each); kT=2 and dt=0.002 make
     # particles migrate between slabs and cross the periodic faces within the run
-    _launch(nproc, {"DOM_N": "8000", "DOM_KT": "2.0", "DOM_STEPS": "60", "DOM_NVT": str(nvt)}, 29511 + nproc + 10 * nvt)
+    # stage == "device": exchange buffers live on the GPU (the RCCL-path plumbing) although gloo carries them
+    _launch(nproc, {"DOM_N": "8000", "DOM_KT": "2.0", "DOM_STEPS": "60", "DOM_NVT": str(nvt), "MDHIP_DOM_STAGE": stage},
+            29511 + nproc + 10 * nvt + (20 if stage else 0))
