@@ -11,9 +11,16 @@
 //   KE / Bussi scale       src/thermostat.jl:20-67
 // Pair enumeration restates CellListMap.jl (un-vendored): translated ghost copies of the
 // particles near a periodic face, every pair accepted iff d^2 <= cutoff^2.
+#ifndef MD_RTC // hiprtc pre-includes its own runtime header and has no include path
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#else
+typedef __hip_internal::uint64_t uint64_t;
+typedef __hip_internal::uint32_t uint32_t;
+typedef __hip_internal::int32_t int32_t;
+typedef __hip_internal::uint16_t uint16_t;
+#endif
 
 #define MD_BLOCK 256
 #define MD_WAVE 64
@@ -727,7 +734,9 @@ __global__ void __launch_bounds__(MD_TILE)
     }
 }
 
+#ifndef MD_RTC // the run-time compiled unit (user potentials) only needs the force kernels
 #include "md_build_tile.hpp"
+#endif
 
 // ------------------------------------------------------------------------------------------
 // The tiled force kernel: same arithmetic and summation order as k_force, neighbour

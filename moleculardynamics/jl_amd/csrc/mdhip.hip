@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "../../../include/mdhip.h"
+#include "md_rtc.hpp"
 
 namespace {
 
@@ -103,6 +104,7 @@ struct md_ctx {
     double rl = 0.0;       // rc + skin
     int pot_kind = POT_LJ;
     PotParams pp{};
+    RtcModule *rtc = nullptr; // run-time compiled kernels of a user potential (POT_CUSTOM)
     bool uniform_sigma = true;
     double sigma_u = 1.0;
     int device = 0;
@@ -416,7 +418,7 @@ void rebuild_t(md_ctx *c)
     c->use_tiles = false;
     c->have_nlist32 = false;
     bool tile_ok = false;
-    const int rs = (c->uniform_sigma && c->pot_kind != POT_POLYDISPERSE) ? 24 : 32; // LDS record stride of the tiled force kernel
+    const int rs = (c->uniform_sigma && c->pot_kind != POT_POLYDISPERSE && c->pot_kind != POT_CUSTOM) ? 24 : 32; // LDS record stride of the tiled force kernel
     auto set_tiles = [&](const Scalars &h) {
         size_t bytes = ((size_t)(h.hmax + 1) * rs + 15) & ~(size_t)15;
         if (!(h.halo_overflow) && bytes <= 150 * 1024) {
@@ -598,6 +600,40 @@ void launch_force_tpu(md_ctx *c, bool want_uw, bool kick, double dt, int step)
 #undef LT
 }
 
+// user potential: the same two kernels, compiled at run time around the user's evaluate()
+void launch_force_custom(md_ctx *c, int dim, bool want_uw, bool kick, double dt, int step)
+{
+    if (!c->rtc) throw HipError("custom potential selected but no compiled module (md_set_potential_source)");
+    int n = (int)c->n;
+    DevState s = c->dev(c->cur);
+    int nb = c->nblk;
+    prof_begin(c);
+    if (c->use_tiles && c->tile_lds <= 64 * 1024) {
+        const uint16_t *l16 = c->nlist16.p;
+        int maxn = c->maxn;
+        const int32_t *nmt = c->nmax_tile.p;
+        const uint32_t *halo = c->halo.p;
+        int hcap = c->hcap;
+        const int32_t *hc = c->halo_count.p;
+        double *part = c->partials.p;
+        const Scalars *sc = c->scal.p;
+        void *args[] = {&n, &s, &c->pp, &l16, &maxn, &nmt, &halo, &hcap, &hc, &dt, &part, &nb, &sc, &step};
+        HIPCHK(hipModuleLaunchKernel(c->rtc->tile[dim - 2][want_uw][kick], nb, 1, 1, MD_TILE, 1, 1,
+                                     (unsigned)c->tile_lds, c->stream, args, nullptr));
+    } else {
+        if (!c->have_nlist32) throw HipError("custom potential: halo too large for LDS and no 32-bit rows (set MDHIP_NO_FUSED_BUILD=1)");
+        const uint32_t *l32 = c->nlist.p;
+        int maxn = c->maxn;
+        const int32_t *nmt = c->nmax_tile.p;
+        double *part = c->partials.p;
+        const Scalars *sc = c->scal.p;
+        void *args[] = {&n, &s, &c->pp, &l32, &maxn, &nmt, &dt, &part, &nb, &sc, &step};
+        HIPCHK(hipModuleLaunchKernel(c->rtc->global[dim - 2][want_uw][kick], nb, 1, 1, MD_BLOCK, 1, 1, 0, c->stream,
+                                     args, nullptr));
+    }
+    prof_end(c);
+}
+
 template <int D>
 void launch_force_d(md_ctx *c, bool want_uw, bool kick, double dt, int step)
 {
@@ -617,6 +653,9 @@ void launch_force_d(md_ctx *c, bool want_uw, bool kick, double dt, int step)
         break;
     case POT_POLYDISPERSE:
         launch_force_tpu<D, POT_POLYDISPERSE, false>(c, want_uw, kick, dt, step);
+        break;
+    case POT_CUSTOM:
+        launch_force_custom(c, D, want_uw, kick, dt, step);
         break;
     default:
         throw HipError("potential kind not available (custom potentials need md_set_potential_source)");
@@ -847,6 +886,8 @@ int md_destroy(md_ctx *ctx)
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipStreamDestroy(ctx->stream);
     }
+    delete ctx->rtc;
+    ctx->rtc = nullptr;
     for (auto &p : ctx->prof_ev) {
         (void)hipEventDestroy(p.first);
         (void)hipEventDestroy(p.second);
@@ -874,11 +915,18 @@ int md_set_potential_source(md_ctx *ctx, const char *hip_src, const char *entry_
                             int nparams)
 {
     API_BEGIN
-    (void)hip_src;
-    (void)entry_name;
-    (void)params;
-    (void)nparams;
-    throw HipError("md_set_potential_source: run-time compiled potentials are not available in this build");
+    if (!hip_src || !entry_name || !entry_name[0]) throw HipError("md_set_potential_source: source and entry name are required");
+    if (nparams < 0 || nparams > 8 || (nparams > 0 && !params)) throw HipError("md_set_potential_source: at most 8 parameters");
+    for (const char *q = entry_name; *q; ++q)
+        if (!((*q >= 'a' && *q <= 'z') || (*q >= 'A' && *q <= 'Z') || (*q >= '0' && *q <= '9') || *q == '_'))
+            throw HipError("md_set_potential_source: entry name must be a plain identifier");
+    RtcModule *m = rtc_build(hip_src, entry_name); // throws with the compiler log on error
+    delete ctx->rtc;
+    ctx->rtc = m;
+    for (int i = 0; i < 8; ++i) ctx->pp.p[i] = (i < nparams) ? params[i] : 0.0;
+    ctx->pot_kind = POT_CUSTOM;
+    ctx->list_valid = false;
+    configure_potential(ctx);
     API_END
 }
 
