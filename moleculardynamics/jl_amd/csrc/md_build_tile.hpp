@@ -88,24 +88,23 @@ __device__ __forceinline__ int tile_sweep_mark(float xi, float yi, float zi, con
                 hi = mid;
         }
         if (nu == 0 || ucell[lo] != cell) continue; // empty cell
-        int qs = coff[lo], qe = coff[lo + 1];
+        int qs = coff[lo], qe = coff[lo + 1]; // padded range: a multiple of 4 entries, 16-byte aligned
         if (qe - qs > 64) {
             *too_big = true;
             continue;
         }
         qstart[ci] = qs;
         unsigned long long mk = 0ull;
-        for (int q0 = qs; q0 < qe; q0 += MD_SWB) {
-            float xq[MD_SWB], yq[MD_SWB], zq[MD_SWB];
+        for (int q0 = qs; q0 < qe; q0 += 4) {
+            float4 x4 = *(const float4 *)(px + q0);
+            float4 y4 = *(const float4 *)(py + q0);
+            float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (D == 3) z4 = *(const float4 *)(pz + q0);
+            const float xq[4] = {x4.x, x4.y, x4.z, x4.w};
+            const float yq[4] = {y4.x, y4.y, y4.z, y4.w};
+            const float zq[4] = {z4.x, z4.y, z4.z, z4.w};
 #pragma unroll
-            for (int b = 0; b < MD_SWB; ++b) {
-                int q = min(q0 + b, qe - 1);
-                xq[b] = px[q];
-                yq[b] = py[q];
-                if constexpr (D == 3) zq[b] = pz[q];
-            }
-#pragma unroll
-            for (int b = 0; b < MD_SWB; ++b) {
+            for (int b = 0; b < 4; ++b) {
                 int q = q0 + b;
                 float ddx = xq[b] - xi;
                 float ddy = yq[b] - yi;
@@ -115,7 +114,7 @@ __device__ __forceinline__ int tile_sweep_mark(float xi, float yi, float zi, con
                     float ddz = zq[b] - zi;
                     d2 = __builtin_fmaf(ddz, ddz, d2);
                 }
-                bool hit = (q < qe) & (d2 <= rl2f) & (q != self_q);
+                bool hit = (d2 <= rl2f) & (q != self_q); // pad entries are 1e30 away
                 // misses write a per-lane trash byte (one shared trash byte would make ~55 lanes hit
                 // one LDS address per instruction)
                 unsigned char *dst = hit ? (ref + q) : trash;
@@ -161,10 +160,11 @@ __global__ void __launch_bounds__(MD_BT_THREADS)
         if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 10 + (i)] = (long long)clock64(); \
     } while (0)
     MD_STAMP(0);
-    __shared__ float px[MD_SCAP], py[MD_SCAP], pz[MD_SCAP];
+    __shared__ __attribute__((aligned(16))) float px[MD_SCAP], py[MD_SCAP], pz[MD_SCAP];
     __shared__ uint16_t newidx[MD_SCAP];
     __shared__ unsigned char ref[MD_SCAP];
     __shared__ int ccell[MD_NCMAX], ucell[MD_NCMAX], coff[MD_NCMAX + 2];
+    __shared__ unsigned char ccnt[MD_NCMAX]; // real (unpadded) population of unique cell u (<= 64)
     __shared__ int cntA[MD_TILE];
     __shared__ int sh_misc[4];
     __shared__ int sh_scan[16];
@@ -244,6 +244,8 @@ __global__ void __launch_bounds__(MD_BT_THREADS)
     MD_STAMP(2);
     // unique cells + staging offsets: each thread owns per_c consecutive sorted entries
     const int per_c = (M + MD_BT_THREADS - 1) / MD_BT_THREADS;
+    // (each cell's staged range is padded to a multiple of 4 entries so that the sweep can read
+    // four coordinates with one 16-byte LDS load; pad entries sit far away and never hit)
     int my_nu = 0, my_cnt = 0;
     for (int q = 0; q < per_c; ++q) {
         int i = tid * per_c + q;
@@ -251,7 +253,7 @@ __global__ void __launch_bounds__(MD_BT_THREADS)
             int c = ccell[i];
             if (c != MD_INF_CELL && (i == 0 || ccell[i - 1] != c)) {
                 ++my_nu;
-                my_cnt += cell_end[c] - cell_start[c];
+                my_cnt += (cell_end[c] - cell_start[c] + 3) & ~3;
             }
         }
     }
@@ -265,8 +267,9 @@ __global__ void __launch_bounds__(MD_BT_THREADS)
             if (c != MD_INF_CELL && (i == 0 || ccell[i - 1] != c)) {
                 ucell[base_nu] = c;
                 coff[base_nu] = base_S;
+                ccnt[base_nu] = cell_end[c] - cell_start[c];
                 ++base_nu;
-                base_S += cell_end[c] - cell_start[c];
+                base_S += (cell_end[c] - cell_start[c] + 3) & ~3;
             }
         }
     }
@@ -295,11 +298,17 @@ __global__ void __launch_bounds__(MD_BT_THREADS)
             else
                 hi = mid;
         }
-        int slot = cell_start[ucell[lo]] + (i - coff[lo]);
-        double4 p = P[slot];
-        px[i] = (float)(p.x - org.x);
-        py[i] = (float)(p.y - org.y);
-        if constexpr (D == 3) pz[i] = (float)(p.z - org.z);
+        int off = i - coff[lo];
+        if (off < (int)ccnt[lo]) {
+            double4 p = P[cell_start[ucell[lo]] + off];
+            px[i] = (float)(p.x - org.x);
+            py[i] = (float)(p.y - org.y);
+            if constexpr (D == 3) pz[i] = (float)(p.z - org.z);
+        } else {
+            px[i] = 1.0e30f; // pad entry
+            py[i] = 1.0e30f;
+            if constexpr (D == 3) pz[i] = 1.0e30f;
+        }
     }
     // this particle's own index in the staged image (its cell is its own neighbour, so it is staged)
     int self_q = -1;
