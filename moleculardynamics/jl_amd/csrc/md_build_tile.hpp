@@ -63,11 +63,11 @@ __device__ __forceinline__ int block_excl_scan(int v, int *lds, int *total)
 #define MD_HALF_CELLS 14
 
 template <int D>
-__device__ __forceinline__ int tile_sweep_mark(float xi, float yi, float zi, const int *ec, const BoxGrid &g,
-                                               float rl2f, int self_q, int n0, int n1, const float *px,
-                                               const float *py, const float *pz, const int *ucell, const int *coff,
-                                               int nu, unsigned char *ref, unsigned char *trash,
-                                               unsigned long long *mask, int *qstart, bool *too_big)
+__device__ __forceinline__ int tile_sweep_mark(float xi, float yi, float zi, const uint16_t *ctab_row, float rl2f,
+                                               int self_q, int n0, int n1, const float *px, const float *py,
+                                               const float *pz, const int *coff, unsigned char *ref,
+                                               unsigned char *trash, unsigned long long *mask, int *qstart,
+                                               bool *too_big)
 {
     int cnt = 0;
 #pragma unroll
@@ -76,18 +76,8 @@ __device__ __forceinline__ int tile_sweep_mark(float xi, float yi, float zi, con
         qstart[ci] = 0;
         int nbi = n0 + ci;
         if (nbi >= n1) continue;
-        int dx = nbi % 3 - 1, dy = (nbi / 3) % 3 - 1, dz = (D == 3) ? nbi / 9 - 1 : 0;
-        int e[3] = {ec[0] + dx, ec[1] + dy, (D == 3) ? ec[2] + dz : 0};
-        int cell = ext_linear(e, g);
-        int lo = 0, hi = nu;
-        while (hi - lo > 1) {
-            int mid = (lo + hi) >> 1;
-            if (ucell[mid] <= cell)
-                lo = mid;
-            else
-                hi = mid;
-        }
-        if (nu == 0 || ucell[lo] != cell) continue; // empty cell
+        int lo = ctab_row[nbi];
+        if (lo == 0xffff) continue; // empty cell
         int qs = coff[lo], qe = coff[lo + 1]; // padded range: a multiple of 4 entries, 16-byte aligned
         if (qe - qs > 64) {
             *too_big = true;
@@ -165,6 +155,8 @@ __global__ void __launch_bounds__(MD_BT_THREADS)
     __shared__ unsigned char ref[MD_SCAP];
     __shared__ int ccell[MD_NCMAX], ucell[MD_NCMAX], coff[MD_NCMAX + 2];
     __shared__ unsigned char ccnt[MD_NCMAX]; // real (unpadded) population of unique cell u (<= 64)
+    __shared__ int ncand[MD_NCMAX];           // neighbour cell of candidate t = (owned cell ci, offset nb), unsorted
+    __shared__ uint16_t ctab[MD_NCMAX];       // its index in ucell[] (0xffff: empty): shared by all lanes of cell ci
     __shared__ int cntA[MD_TILE];
     __shared__ int sh_misc[4];
     __shared__ int sh_scan[16];
@@ -222,6 +214,7 @@ __global__ void __launch_bounds__(MD_BT_THREADS)
             if (cell_end[nc] > cell_start[nc]) v = nc;
         }
         ccell[t] = v;
+        if (t < MD_NCMAX) ncand[t] = v;
     }
     __syncthreads();
     MD_STAMP(1);
@@ -287,6 +280,27 @@ __global__ void __launch_bounds__(MD_BT_THREADS)
         if (tid == 0) atomicOr(&sc->halo_overflow, 2);
         return;
     }
+    // 1c. resolve every (owned cell, neighbour offset) to its unique-cell index once per tile; all
+    // lanes of a cell share the result (per-lane lookups cost more VALU time than the distance tests)
+    for (int t = tid; t < nne * NNB; t += MD_BT_THREADS) {
+        int cell = ncand[t];
+        uint16_t u16 = 0xffffu;
+        if (cell != MD_INF_CELL && nu > 0) {
+            int lo = 0, hi = nu;
+            while (hi - lo > 1) {
+                int mid = (lo + hi) >> 1;
+                if (ucell[mid] <= cell)
+                    lo = mid;
+                else
+                    hi = mid;
+            }
+            if (ucell[lo] == cell) u16 = (uint16_t)lo;
+        }
+        ctab[t] = u16;
+    }
+    int myci = 0; // index of my cell in the tile's list of owned cells
+    for (int q = 0; q < nne; ++q)
+        if (sh_ne[q] == mycell) myci = q;
     MD_STAMP(3);
     // 2. stage (fp32, relative to the tile origin)
     for (int i = tid; i < S; i += MD_BT_THREADS) {
@@ -310,18 +324,12 @@ __global__ void __launch_bounds__(MD_BT_THREADS)
             if constexpr (D == 3) pz[i] = 1.0e30f;
         }
     }
+    __syncthreads();
     // this particle's own index in the staged image (its cell is its own neighbour, so it is staged)
     int self_q = -1;
     if (active) {
-        int lo = 0, hi = nu;
-        while (hi - lo > 1) {
-            int mid = (lo + hi) >> 1;
-            if (ucell[mid] <= mycell)
-                lo = mid;
-            else
-                hi = mid;
-        }
-        self_q = coff[lo] + (k - cell_start[mycell]);
+        int uc = ctab[myci * NNB + (NNB >> 1)]; // centre offset (0,0,0)
+        self_q = coff[uc] + (k - cell_start[mycell]);
     }
     __syncthreads();
     MD_STAMP(4);
@@ -334,7 +342,7 @@ __global__ void __launch_bounds__(MD_BT_THREADS)
     int cnt = 0;
     bool too_big = false;
     if (active)
-        cnt = tile_sweep_mark<D>(xi, yi, zi, ec, g, rl2f, self_q, n0, n1, px, py, pz, ucell, coff, nu, ref,
+        cnt = tile_sweep_mark<D>(xi, yi, zi, ctab + myci * NNB, rl2f, self_q, n0, n1, px, py, pz, coff, ref,
                                  sh_trash + 4 * tid, hmask, qstart, &too_big);
     else {
 #pragma unroll
