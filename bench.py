@@ -218,6 +218,7 @@ def main():
             "global_particles": total_particles,
             "avg_list_candidates": st1["avg_neighbors"],
             "tiled_force_kernel": bool(st1["tiled"]),
+            "prunes_in_timed_region": st1["prunes"] - st0["prunes"],
             "max_tile_halo": st1["max_halo"],
         },
         "roofline": {

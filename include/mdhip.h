@@ -66,6 +66,12 @@ int md_set_potential_source(md_ctx *ctx, const char *hip_src, const char *entry_
  * of every step is unchanged (pairs are still filtered by d^2 <= list_cutoff^2).          */
 int md_set_skin(md_ctx *ctx, double skin);
 
+/* Dynamic pruning of the rows: every few steps the rows the force kernel walks are refreshed from
+ * the Verlet rows, keeping the entries within list_cutoff + inner_skin at that moment.  Results are
+ * unchanged (only sure misses are dropped, order kept); inner_skin = 0 turns it off (the default:
+ * at N = 2^20 the prune pass still costs more than the shorter rows save). */
+int md_set_inner_skin(md_ctx *ctx, double inner_skin);
+
 /* State transfer; any pointer may be NULL (= leave that array as it is on the device).
  * x, v, f: d x N doubles; images: d x N int32; diameters: N doubles.
  * Mirrors the fields of SimulationState / EnergyAndForces: src/types.jl:15-32,53-57.
@@ -117,6 +123,7 @@ typedef struct {
     double force_ms;        /* their summed duration, HIP events on the handle's stream */
     int64_t max_halo;       /* largest per-tile halo (LDS-staged neighbours) of the last build */
     int64_t tiled;          /* 1 if the LDS-tiled force kernel is in use, 0 if the global-gather one */
+    int64_t prunes;         /* row prunes (inner-list refreshes) since create */
 } md_stats;
 int md_profile(md_ctx *ctx, int enable);
 int md_get_stats(md_ctx *ctx, md_stats *out);

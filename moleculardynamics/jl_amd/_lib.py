@@ -15,6 +15,7 @@ MD_NVE, MD_NVT = 0, 1
 # every symbol include/mdhip.h declares
 EXPORTS = [
     "md_create", "md_destroy", "md_last_error", "md_set_potential", "md_set_potential_source", "md_set_skin",
+    "md_set_inner_skin",
     "md_upload", "md_download", "md_compute_forces", "md_neighbor_pairs", "md_run", "md_kinetic",
     "md_scale_velocities", "md_profile", "md_get_stats", "md_version",
     "md_create_domain", "md_dom_set_uniform", "md_dom_upload", "md_dom_download", "md_dom_migrate_pack",
@@ -27,7 +28,7 @@ EXPORTS = [
 class MdStats(C.Structure):
     _fields_ = [("steps", C.c_int64), ("rebuilds", C.c_int64), ("violations", C.c_int64), ("n_ghost", C.c_int64),
                 ("max_neighbors", C.c_int64), ("avg_neighbors", C.c_double), ("force_launches", C.c_int64),
-                ("force_ms", C.c_double), ("max_halo", C.c_int64), ("tiled", C.c_int64)]
+                ("force_ms", C.c_double), ("max_halo", C.c_int64), ("tiled", C.c_int64), ("prunes", C.c_int64)]
 
 
 class MdhipError(RuntimeError):
@@ -60,6 +61,8 @@ def load():
     L.md_set_potential_source.restype = C.c_int
     L.md_set_skin.argtypes = [vp, C.c_double]
     L.md_set_skin.restype = C.c_int
+    L.md_set_inner_skin.argtypes = [vp, C.c_double]
+    L.md_set_inner_skin.restype = C.c_int
     L.md_upload.argtypes = [vp, dp, dp, dp, ip, dp]
     L.md_upload.restype = C.c_int
     L.md_download.argtypes = [vp, dp, dp, dp, ip]

@@ -147,6 +147,16 @@ struct md_ctx {
     bool list_valid = false;
     int64_t steps_since_build = 0;
     int64_t target_interval = 8;
+    // dynamic pruning of the rows (single-GPU handles with a skin): inner rows used by the force kernel
+    double inner_skin_req = 0.0; // off by default: the prune kernel's compaction currently costs more than it saves
+    double inner_skin = 0.0;
+    bool inner_valid = false;
+    DBuf<double> x1[3];
+    DBuf<uint16_t> nlist16_in;
+    DBuf<int32_t> nmax_tile_in;
+    int64_t steps_since_prune = 0;
+    int64_t prune_target = 6;
+    int64_t st_prunes = 0;
 
     // stats / profiling
     int64_t st_steps = 0, st_rebuilds = 0, st_viol = 0;
@@ -168,6 +178,7 @@ struct md_ctx {
             s.f[c] = b.f[c].p;
             s.img[c] = b.img[c].p;
             s.x0[c] = b.x0[c].p;
+            s.x1[c] = (inner_valid && x1[c].p) ? x1[c].p : b.x0[c].p;
         }
         s.id = b.id.p;
         return s;
@@ -204,6 +215,14 @@ __global__ void k_reset_flags(Scalars *sc)
     sc->halo_overflow = 0;
     sc->dbg_rmax = 0;
     sc->dbg_smax = 0;
+    sc->d1max2_bits = 0ull;
+}
+
+// before a prune: the displacement maximum is recomputed, and a recorded violation is consumed
+__global__ void k_reset_d1(Scalars *sc)
+{
+    sc->d1max2_bits = 0ull;
+    sc->first_viol = MD_NO_VIOLATION;
 }
 
 void alloc_state(md_ctx *c, int which, int64_t cap)
@@ -351,6 +370,9 @@ void ensure_capacity(md_ctx *c, int64_t need_next)
     c->img_off.ensure(newcap + 2);
     c->newslot.ensure(newcap + 1);
 }
+
+void launch_prune(md_ctx *c);
+void launch_ghost_update(md_ctx *c, int step);
 
 template <int D>
 void rebuild_t(md_ctx *c)
@@ -505,6 +527,16 @@ void rebuild_t(md_ctx *c)
     c->list_valid = true;
     c->steps_since_build = 0;
     c->st_rebuilds++;
+    c->inner_valid = false;
+    bool prune_on = c->use_tiles && !c->dom.on && c->skin > 0.0 && c->inner_skin_req > 0.0 &&
+                    c->inner_skin_req < 0.9 * c->skin;
+    if (prune_on) {
+        c->inner_skin = c->inner_skin_req;
+        for (int d = 0; d < c->dim; ++d) c->x1[d].ensure(c->ncap);
+        c->nlist16_in.ensure((size_t)c->ntiles * c->maxn * 64);
+        c->nmax_tile_in.ensure(c->ntiles);
+        launch_prune(c);
+    }
 }
 
 void rebuild(md_ctx *c)
@@ -551,6 +583,8 @@ void prof_collect(md_ctx *c)
 template <int D, int POT, bool UNIFORM>
 void launch_force_tpu(md_ctx *c, bool want_uw, bool kick, double dt, int step)
 {
+    const uint16_t *rows16 = c->inner_valid ? c->nlist16_in.p : c->nlist16.p;
+    const int32_t *rowmax = c->inner_valid ? c->nmax_tile_in.p : c->nmax_tile.p;
     int n = (int)c->n;
     DevState s = c->dev(c->cur);
     int nb = c->nblk;
@@ -567,7 +601,7 @@ void launch_force_tpu(md_ctx *c, bool want_uw, bool kick, double dt, int step)
                                        (int)(160 * 1024 - 256)));                                                   \
             attr_bytes = 160 * 1024;                                                                                \
         }                                                                                                           \
-        kfn<<<nb, MD_TILE, c->tile_lds, c->stream>>>(n, s, c->pp, c->nlist16.p, c->maxn, c->nmax_tile.p, c->halo.p, \
+        kfn<<<nb, MD_TILE, c->tile_lds, c->stream>>>(n, s, c->pp, rows16, c->maxn, rowmax, c->halo.p,              \
                                                      c->hcap, c->halo_count.p, dt, c->partials.p, nb, c->scal.p,    \
                                                      step);                                                         \
     } while (0)
@@ -609,9 +643,9 @@ void launch_force_custom(md_ctx *c, int dim, bool want_uw, bool kick, double dt,
     int nb = c->nblk;
     prof_begin(c);
     if (c->use_tiles && c->tile_lds <= 64 * 1024) {
-        const uint16_t *l16 = c->nlist16.p;
+        const uint16_t *l16 = c->inner_valid ? c->nlist16_in.p : c->nlist16.p;
         int maxn = c->maxn;
-        const int32_t *nmt = c->nmax_tile.p;
+        const int32_t *nmt = c->inner_valid ? c->nmax_tile_in.p : c->nmax_tile.p;
         const uint32_t *halo = c->halo.p;
         int hcap = c->hcap;
         const int32_t *hc = c->halo_count.p;
@@ -670,22 +704,67 @@ void launch_force(md_ctx *c, bool want_uw, bool kick, double dt, int step)
         launch_force_d<2>(c, want_uw, kick, dt, step);
 }
 
-void launch_kickdrift(md_ctx *c, bool nvt, double dt, double thr2, int step)
+void launch_kickdrift(md_ctx *c, bool nvt, double dt, bool check, int step)
 {
     int n = (int)c->n;
     DevState s = c->dev(c->cur);
     int nb = c->nblk;
+    // displacement limits (see k_kickdrift); INFINITY disables the check (rebuild-every-step mode)
+    double skin_half = check ? 0.5 * c->skin : INFINITY;
+    double inner_half = check ? (c->inner_valid ? 0.5 * c->inner_skin : 0.5 * c->skin) : INFINITY;
     if (c->dim == 3) {
         if (nvt)
-            k_kickdrift<3, true><<<nb, MD_BLOCK, 0, c->stream>>>(n, s, dt, thr2, c->scal.p, step);
+            k_kickdrift<3, true><<<nb, MD_BLOCK, 0, c->stream>>>(n, s, dt, skin_half, inner_half, c->scal.p, step);
         else
-            k_kickdrift<3, false><<<nb, MD_BLOCK, 0, c->stream>>>(n, s, dt, thr2, c->scal.p, step);
+            k_kickdrift<3, false><<<nb, MD_BLOCK, 0, c->stream>>>(n, s, dt, skin_half, inner_half, c->scal.p, step);
     } else {
         if (nvt)
-            k_kickdrift<2, true><<<nb, MD_BLOCK, 0, c->stream>>>(n, s, dt, thr2, c->scal.p, step);
+            k_kickdrift<2, true><<<nb, MD_BLOCK, 0, c->stream>>>(n, s, dt, skin_half, inner_half, c->scal.p, step);
         else
-            k_kickdrift<2, false><<<nb, MD_BLOCK, 0, c->stream>>>(n, s, dt, thr2, c->scal.p, step);
+            k_kickdrift<2, false><<<nb, MD_BLOCK, 0, c->stream>>>(n, s, dt, skin_half, inner_half, c->scal.p, step);
     }
+}
+
+template <int D, bool UNIFORM>
+void launch_prune_t(md_ctx *c)
+{
+    static size_t attr_bytes = 0;
+    auto kfn = k_prune<D, UNIFORM>;
+    if (c->tile_lds > attr_bytes) {
+        HIPCHK(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - 256)));
+        attr_bytes = 160 * 1024;
+    }
+    double rin = c->rc + c->inner_skin;
+    DevState s = c->dev(c->cur);
+    for (int d = 0; d < 3; ++d) s.x1[d] = c->x1[d].p; // the prune writes the new reference positions
+    k_reset_d1<<<1, 1, 0, c->stream>>>(c->scal.p);
+    // after a displacement violation the step's ghost refresh was skipped along with its force half:
+    // bring the ghost copies up to the owners' current positions before measuring distances
+    launch_ghost_update(c, -1);
+    kfn<<<c->nblk, MD_TILE, c->tile_lds, c->stream>>>((int)c->n, s, rin * rin, c->nlist16.p, c->nlist16_in.p, c->maxn,
+                                                      c->nmax_tile.p, c->nmax_tile_in.p, c->halo.p, c->hcap,
+                                                      c->halo_count.p, c->scal.p);
+}
+
+// refresh the inner rows from the outer ones at the current positions
+void launch_prune(md_ctx *c)
+{
+    bool uniform_kernel = c->tile_rs == 24;
+    if (c->dim == 3) {
+        if (uniform_kernel)
+            launch_prune_t<3, true>(c);
+        else
+            launch_prune_t<3, false>(c);
+    } else {
+        if (uniform_kernel)
+            launch_prune_t<2, true>(c);
+        else
+            launch_prune_t<2, false>(c);
+    }
+    HIPCHK(hipGetLastError());
+    c->inner_valid = true;
+    c->steps_since_prune = 0;
+    c->st_prunes++;
 }
 
 void launch_ghost_update(md_ctx *c, int step)
@@ -790,6 +869,7 @@ static int create_common(int dim, int64_t n_global, int64_t n_cap, bool domain, 
         }
         if (const char *e = getenv("MDHIP_NO_TILES")) ctx->allow_tiles = !(e[0] == '1');
         if (const char *e = getenv("MDHIP_NO_FUSED_BUILD")) ctx->allow_fused_build = !(e[0] == '1');
+        if (const char *e = getenv("MDHIP_INNER_SKIN")) ctx->inner_skin_req = atof(e);
         // default potential: LennardJones() -- src/potentials.jl:52-64
         ctx->pot_kind = POT_LJ;
         ctx->pp.p[0] = 1.0;
@@ -950,6 +1030,17 @@ int md_set_skin(md_ctx *ctx, double skin)
         }
     }
     ctx->target_interval = 8;
+    ctx->prune_target = 6;
+    API_END
+}
+
+int md_set_inner_skin(md_ctx *ctx, double inner_skin)
+{
+    API_BEGIN
+    if (!(inner_skin >= 0.0)) throw HipError("md_set_inner_skin: must be >= 0");
+    ctx->inner_skin_req = inner_skin;
+    ctx->list_valid = false;
+    ctx->prune_target = 6;
     API_END
 }
 
@@ -1032,7 +1123,8 @@ int md_compute_forces(md_ctx *ctx, double *energy, double *virial)
 {
     API_BEGIN
     if (!ctx->list_valid) rebuild(ctx);
-    launch_force(ctx, true, false, 0.0, -1);
+    launch_force(ctx, true, false, 0.0, -1); // (inner rows, if any, were pruned at these very positions or are
+                                             //  still valid: md_run keeps them so)
     launch_finalize(ctx, true, false, 1.0, 0.0, -1);
     HIPCHK(hipGetLastError());
     Scalars h = read_scalars(ctx);
@@ -1111,42 +1203,75 @@ int md_run(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, double tau, dou
     if (ctx->skin <= 0.0) {
         // literal reference cadence: a fresh linked-cell build every step
         for (int t = 0; t < (int)nsteps; ++t) {
-            launch_kickdrift(ctx, nvt, dt, INFINITY, t);
+            launch_kickdrift(ctx, nvt, dt, false, t);
             rebuild(ctx);
             force_part(t);
         }
     } else {
-        double thr2 = (0.5 * ctx->skin) * (0.5 * ctx->skin);
+        // Chunks of steps are enqueued without host round-trips.  The drift kernel records the first
+        // step at which a particle left the validity radius of the rows in use (`first_viol`); every
+        // later kernel of the chunk skips itself.  With pruning on, the rows in use are the inner
+        // rows: refreshing them is a cheap prune; the outer rows are rebuilt only when the
+        // displacement accumulated since the build (d1, measured by the prune) nears skin/2.
+        auto refresh = [&](double d1) {
+            bool pruning = ctx->inner_valid;
+            // the next prune interval may add up to inner_skin/2 (+ a step of overshoot) to d1
+            bool need_build = !pruning || (d1 + 0.75 * ctx->inner_skin >= 0.5 * ctx->skin);
+            if (need_build)
+                rebuild(ctx); // (prunes right after when pruning is on)
+            else
+                launch_prune(ctx);
+        };
         int s = 0;
         while (s < (int)nsteps) {
-            int64_t room = std::max<int64_t>(1, ctx->target_interval - ctx->steps_since_build);
+            bool pruning = ctx->inner_valid;
+            int64_t target = pruning ? ctx->prune_target : ctx->target_interval;
+            int64_t since = pruning ? ctx->steps_since_prune : ctx->steps_since_build;
+            int64_t room = std::max<int64_t>(1, target - since);
             int chunk_end = (int)std::min<int64_t>(nsteps, (int64_t)s + room);
             for (int t = s; t < chunk_end; ++t) {
-                launch_kickdrift(ctx, nvt, dt, thr2, t);
+                launch_kickdrift(ctx, nvt, dt, true, t);
                 launch_ghost_update(ctx, t);
                 force_part(t);
             }
             HIPCHK(hipGetLastError());
             Scalars h = read_scalars(ctx);
+            double d1 = 0.0;
+            {
+                unsigned long long bits = h.d1max2_bits;
+                double d12;
+                memcpy(&d12, &bits, sizeof d12);
+                d1 = std::sqrt(d12);
+            }
             if (h.first_viol < chunk_end) {
-                // some particle moved skin/2 during step m's drift: everything from its force
-                // evaluation on was skipped on the device.  Rebuild at the drifted positions
-                // and resume with the force half of step m.
+                // everything from step m's force evaluation on was skipped on the device: refresh the
+                // rows at the drifted positions and resume with the force half of step m
                 int m = h.first_viol;
+                if (m < s) throw HipError("internal: stale displacement-violation index");
                 ctx->st_viol++;
-                int64_t observed = ctx->steps_since_build + (m - s) + 1;
-                ctx->target_interval = std::max<int64_t>(2, (observed * 4) / 5);
-                rebuild(ctx);
+                int64_t observed = since + (m - s) + 1;
+                int64_t nt = std::max<int64_t>(2, (observed * 4) / 5);
+                if (pruning)
+                    ctx->prune_target = nt;
+                else
+                    ctx->target_interval = nt;
+                ctx->steps_since_build += (m - s) + 1;
+                refresh(d1);
                 force_part(m);
                 s = m + 1;
             } else {
                 ctx->steps_since_build += chunk_end - s;
+                ctx->steps_since_prune += chunk_end - s;
                 s = chunk_end;
-                if (s < (int)nsteps && ctx->steps_since_build >= ctx->target_interval) {
-                    // scheduled rebuild just ahead of the expected violation; creep the
-                    // interval up so it tracks the true one from below
-                    rebuild(ctx);
-                    ctx->target_interval += 1;
+                since += room;
+                if (s < (int)nsteps && since >= target) {
+                    // scheduled refresh just ahead of the expected violation; creep the interval up so
+                    // that it tracks the true one from below
+                    refresh(d1);
+                    if (pruning)
+                        ctx->prune_target += 1;
+                    else
+                        ctx->target_interval += 1;
                 }
             }
         }
@@ -1231,6 +1356,7 @@ int md_get_stats(md_ctx *ctx, md_stats *out)
         for (int32_t v : h) sum += v;
         out->avg_neighbors = sum / (double)ctx->n;
     }
+    out->prunes = ctx->st_prunes;
     out->max_halo = ctx->use_tiles ? ctx->hstride : 0;
     out->tiled = ctx->use_tiles ? 1 : 0;
     out->force_launches = ctx->prof_launch_acc;
@@ -1535,8 +1661,7 @@ int md_dom_step_begin(md_ctx *ctx, double dt, int *violated)
     auto &d = ctx->dom;
     hipStream_t st = ctx->stream;
     k_reset_viol<<<1, 1, 0, st>>>(ctx->scal.p);
-    double thr2 = (0.5 * ctx->skin) * (0.5 * ctx->skin);
-    if (ctx->n > 0) launch_kickdrift(ctx, true, dt, thr2, 0);
+    if (ctx->n > 0) launch_kickdrift(ctx, true, dt, true, 0);
     k_set_scale<<<1, 1, 0, st>>>(ctx->scal.p, 1.0);
     DevState s = ctx->dev(ctx->cur);
     double shift_l = (d.rank == 0) ? ctx->L[0] : 0.0;

@@ -82,6 +82,9 @@ class MDDevice:
     def set_skin(self, skin):
         self._chk(self._L.md_set_skin(self._h, float(skin)))
 
+    def set_inner_skin(self, inner_skin):
+        self._chk(self._L.md_set_inner_skin(self._h, float(inner_skin)))
+
     # -- state ----------------------------------------------------------------------------
     def upload(self, x=None, v=None, f=None, images=None, diameters=None):
         shp = (self.n, self.dim)

@@ -359,3 +359,26 @@ def test_user_potential_source(oracle):
             return ("source", USER_LJ_SRC, "user_lj", [1.0, 2.5])
 
     assert UserLJ().device_spec()[0] == "source"
+
+
+def test_pruning_changes_nothing():
+    """Dynamic pruning (opt-in) only drops candidates that cannot interact before the next prune and
+    keeps the order of the rest, so each force evaluation is unchanged.  (The runs are not bit-identical
+    as a whole: rebuilds happen at different steps, which reorders particles and hence sums.)"""
+    from moleculardynamics.jl_amd import MDDevice
+    s = lj_system(32768, kT=2.5)
+    out = []
+    for inner in (0.0, 0.12, 0.05):
+        with MDDevice(3, s["n"], s["box"], 2.5) as d:
+            d.set_potential(0, LJ)
+            d.set_inner_skin(inner)
+            d.upload(s["x"], s["v"], s["f"], s["img"], s["diam"])
+            uwk = d.run(150, 0.002)
+            x, v, f, img = d.download()
+            st = d.stats()
+        out.append((x, v, f, uwk, st))
+    assert out[0][4]["prunes"] == 0 and out[1][4]["prunes"] > 5 and out[2][4]["prunes"] > out[1][4]["prunes"]
+    for x, v, f, uwk, st in out[1:]:
+        assert np.abs(x - out[0][0]).max() <= 1e-9 and np.abs(v - out[0][1]).max() <= 1e-9
+        _check_forces(f, out[0][2], 1e-9)
+        assert abs(uwk[0] - out[0][3][0]) <= 1e-10 * abs(out[0][3][0])
