@@ -32,6 +32,17 @@ STEP_BYTES = {"nve": 332.0, "nvt": 380.0}   # algorithmi
 FORCE_KERNEL_BYTES = 96.0
 
 
+def measured_traffic():
+    """HBM bytes per launch of the dominant kernel from the PMC passes (FETCH_SIZE / WRITE_SIZE collected in
+    separate rocprofv3 --pmc runs of this same command, gfx950 read-side correction applied); the summary
+    lives in profiles/ because counters cannot be collected from inside the benchmark process."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic_k_force_tile.json")) as f:
+            return json.load(f)["traffic_bytes_corrected"]
+    except Exception:
+        return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -228,7 +239,7 @@ def main():
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": None,
+            "traffic": measured_traffic() if (world == 1 and a.n == 1048576) else None,
             "kernel_ms": kern_ms,
             "kernel_launches": launches,
             "bytes_per_launch": FORCE_KERNEL_BYTES * a.n,
