@@ -1,0 +1,126 @@
+"""-m gpu: edge cases of the device path -- tiny systems, clustered (ragged) neighbour counts that
+overflow the row capacity, positions uploaded outside the box, partial uploads, error reporting."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+LJ = [1.0, 1.0, 2.5]
+
+
+def _forces(oracle, x, box, cutoff, diam=None, kind=0, params=LJ):
+    from moleculardynamics.jl_amd import MDDevice
+    n, d = x.shape
+    diam = np.ones(n) if diam is None else diam
+    pot = oracle.make_pot(kind, params)
+    f_ref, u_ref, w_ref, pairs_ref = oracle.forces_brute(x, box, cutoff, pot, diam, want_pairs=True)
+    with MDDevice(d, n, box, cutoff) as dev:
+        dev.set_potential(kind, params)
+        dev.upload(x, np.zeros_like(x), np.zeros_like(x), np.zeros((n, d), dtype=np.int32), diam)
+        u, w = dev.compute_forces()
+        _, _, f, _ = dev.download()
+        pairs = dev.neighbor_pairs()
+        st = dev.stats()
+    pr = pairs_ref[np.lexsort((pairs_ref[:, 1], pairs_ref[:, 0]))] if len(pairs_ref) else pairs_ref.reshape(0, 2)
+    assert np.array_equal(pairs.reshape(-1, 2)[: len(pr)], pr) and len(pairs) == len(pr)
+    scale = max(1.0, np.abs(f_ref).max())
+    assert np.abs(f - f_ref).max() <= 1e-11 * scale
+    assert abs(u - u_ref) <= 1e-12 * max(1.0, abs(u_ref)) and abs(w - w_ref) <= 1e-12 * max(1.0, abs(w_ref))
+    return st
+
+
+@pytest.mark.parametrize("n", [2, 3, 7, 64, 65, 257])
+def test_tiny_systems(oracle, n):
+    rng = np.random.default_rng(n)
+    box = np.array([9.0, 9.0, 9.0])
+    # a loose jittered-grid cluster plus the box corners: exercises empty cells, partial tiles and waves
+    m = int(np.ceil(n ** (1 / 3)))
+    g = np.stack(np.meshgrid(*[np.arange(m)] * 3, indexing="ij"), -1).reshape(-1, 3)[:n].astype(float)
+    x = 1.2 + g * (6.0 / max(m, 2)) * 0.95 + rng.uniform(-0.03, 0.03, (n, 3))
+    x[0] = [0.05, 0.05, 0.05]
+    if n > 2:
+        x[1] = [8.95, 8.95, 8.95]      # interacts with particle 0 through the periodic corner
+    _forces(oracle, x, box, 2.5)
+
+
+def test_no_pairs_at_all(oracle):
+    box = np.array([30.0, 30.0, 30.0])
+    x = np.array([[1.0, 1.0, 1.0], [15.0, 15.0, 15.0], [8.0, 22.0, 3.0]])
+    from moleculardynamics.jl_amd import MDDevice
+    with MDDevice(3, 3, box, 2.5) as dev:
+        dev.upload(x, np.zeros_like(x), np.zeros_like(x), np.zeros((3, 3), dtype=np.int32), np.ones(3))
+        u, w = dev.compute_forces()
+        _, _, f, _ = dev.download()
+        assert u == 0.0 and w == 0.0 and not f.any() and len(dev.neighbor_pairs()) == 0
+        dev.upload(v=np.array([[1.0, 0, 0], [0, 2.0, 0], [0, 0, -3.0]]))
+        assert dev.kinetic() == pytest.approx(0.5 * 14.0)
+        dev.scale_velocities(2.0)
+        assert dev.kinetic() == pytest.approx(0.5 * 56.0)
+        U, W, K = dev.run(10, 0.01)      # free flight
+        x2, v2, _, img = dev.download()
+        assert K == pytest.approx(28.0) and np.allclose(x2[0], [1.2, 1.0, 1.0]) and np.allclose(x2[2], [8, 22, 2.4])
+
+
+def test_dense_cluster_overflows_the_row_capacity(oracle):
+    """A dense blob in a dilute box: neighbour counts far above the density-based row capacity force
+    the build to grow its rows and retry; ragged rows (blob vs gas) share tiles."""
+    rng = np.random.default_rng(11)
+    box = np.array([24.0, 24.0, 24.0])
+    g = np.stack(np.meshgrid(*[np.arange(9)] * 3, indexing="ij"), -1).reshape(-1, 3) * 0.72 + 8.0   # 729 in a 5.8 cube
+    gas = rng.uniform(0, 24, (300, 3))
+    gas = gas[np.all((gas < 6.5) | (gas > 15.5), axis=1)][:120]
+    x = np.concatenate([g + rng.uniform(-0.02, 0.02, g.shape), gas])
+    st = _forces(oracle, x, box, 2.5)
+    assert st["max_neighbors"] > 150          # grew beyond the initial estimate
+    assert st["avg_neighbors"] > 100
+
+
+def test_positions_outside_the_box_and_partial_upload(oracle):
+    from moleculardynamics.jl_amd import MDDevice
+    from tests.util import lj_system
+    s = lj_system(1000)
+    L = s["box"][0]
+    shift = np.random.default_rng(2).integers(-2, 3, (1000, 3))
+    x_out = s["x"] + shift * L                       # same physical configuration, images moved
+    pot = oracle.make_pot(0, LJ)
+    f_ref, u_ref, w_ref, _ = oracle.forces_brute(s["x"], s["box"], 2.5, pot, s["diam"])
+    with MDDevice(3, 1000, s["box"], 2.5) as dev:
+        dev.upload(x_out, s["v"], s["f"], s["img"], s["diam"])
+        u, w = dev.compute_forces()
+        x, v, f, img = dev.download()
+        assert np.array_equal(img, shift)              # wrapped on the first build, images carry the shift
+        assert np.abs(x - s["x"]).max() < 1e-12 * L * 3
+        assert np.abs(f - f_ref).max() <= 1e-9 * np.abs(f_ref).max() and abs(u - u_ref) <= 1e-9 * abs(u_ref)
+        dev.upload(v=2.0 * s["v"])                     # only velocities: everything else stays
+        x2, v2, f2, img2 = dev.download()
+        assert np.array_equal(v2, 2.0 * s["v"]) and np.array_equal(x2, x) and np.array_equal(f2, f)
+
+
+def test_error_reporting():
+    import moleculardynamics.jl_amd as md
+    with pytest.raises(md.MdhipError, match="box too small"):
+        md.MDDevice(3, 100, 6.0, 2.5)
+    with md.MDDevice(3, 100, 12.0, 2.5) as dev:
+        with pytest.raises(md.MdhipError, match="unknown potential kind"):
+            dev.set_potential(7, [1.0])
+        with pytest.raises(md.MdhipError, match="too few parameters"):
+            dev.set_potential(0, [1.0])
+        with pytest.raises(md.MdhipError, match="NVT needs"):
+            dev.run(5, 0.001, 1, 0.1)
+        with pytest.raises(ValueError):
+            dev.upload(x=np.zeros((99, 3)))
+
+
+def test_nvt_temperature_ramp_through_the_driver(tmp_path):
+    """NVT with a callable target (LinearRamp) through run_simulation: the thermostat drags T along the
+    ramp (statistical check), thermo lines at the reference's steps."""
+    import moleculardynamics.jl_amd as md
+    params = md.Parameters(0.8, 4096, 0.002, md.LennardJones())
+    st = md.initialize_state(params, str(tmp_path), random_init=True, cutoff=2.5, rng=np.random.default_rng(1))
+    st.velocities = md.initialize_velocities(2.0, np.random.default_rng(2), 4096, 3)
+    ramp = md.LinearRamp(2.0, 1.0, 400)
+    md.run_simulation(st, params, md.NVT(ramp, 0.05), 600, 100, str(tmp_path), write_trajectory=False)
+    rows = [ln.split() for ln in open(tmp_path / "thermo.txt").read().splitlines()[1:]]
+    assert [int(r[0]) for r in rows] == [0, 100, 200, 300, 400, 500]
+    T = np.array([float(r[2]) for r in rows])
+    assert abs(T[-1] - 1.0) < 0.08 and abs(T[3] - ramp(301)) < 0.15 and T[1] > T[3] > T[5] - 0.05
+    st.system.device.close()
