@@ -741,109 +741,6 @@ __global__ void __launch_bounds__(MD_TILE)
 #endif
 
 // ------------------------------------------------------------------------------------------
-// Dynamic pruning.  The outer rows (built with cutoff + skin) stay valid for ~25 steps but make
-// the force kernel test ~35 % sure misses.  Every few steps this kernel copies each outer row
-// to an inner row, keeping only the entries within cutoff + inner skin NOW (same order: the
-// kept entries are exactly the ones that can contribute before the next prune, so the forces
-// are bit-identical with and without pruning), records the prune-time positions x1 and the
-// largest displacement since the build.  Distance tests only: about a third of a force pass.
-// ------------------------------------------------------------------------------------------
-template <int D, bool UNIFORM>
-__global__ void __launch_bounds__(MD_TILE)
-    k_prune(int n, DevState s, double rin2, const uint16_t *__restrict__ rows_out, uint16_t *__restrict__ rows_in,
-            int maxn, const int32_t *__restrict__ nmax_out, int32_t *__restrict__ nmax_in,
-            const uint32_t *__restrict__ halo, int hcap, const int32_t *__restrict__ halo_count, Scalars *sc)
-{
-    constexpr int RS = UNIFORM ? 24 : 32;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const double4 *__restrict__ P = s.pos;
-    int H = halo_count[bid];
-    const uint32_t *hl = halo + (size_t)bid * hcap;
-    for (int h = threadIdx.x; h <= H; h += MD_TILE) {
-        double4 p = (h < H) ? P[hl[h]] : make_double4(MD_SENTINEL_POS, MD_SENTINEL_POS, MD_SENTINEL_POS, 1.0);
-        double *rec = (double *)(smem + (size_t)h * RS);
-        rec[0] = p.x;
-        rec[1] = p.y;
-        rec[2] = (D == 3) ? p.z : 0.0;
-    }
-    __syncthreads();
-    int k = bid * MD_TILE + threadIdx.x;
-    bool active = k < n;
-    int kk = active ? k : n - 1;
-    int lane = threadIdx.x & 63;
-    int wt = bid * (MD_TILE / 64) + (threadIdx.x >> 6);
-    const ushort4 *row4 = (const ushort4 *)(rows_out + ((size_t)wt * maxn) * 64) + lane;
-    ushort4 *out4 = (ushort4 *)(rows_in + ((size_t)wt * maxn) * 64) + lane;
-    int m = nmax_out[wt];
-    double4 pi = P[kk];
-    const unsigned sent = (unsigned)H * RS;
-    int cnt = 0;
-    unsigned keep[4] = {sent, sent, sent, sent};
-    ushort4 jnext = row4[0];
-    for (int r = 0; r < m; r += 4) {
-        ushort4 jj = jnext;
-        int rn = (r + 4 < m) ? r + 4 : r;
-        jnext = row4[(size_t)(rn >> 2) * 64];
-        unsigned o[4] = {jj.x, jj.y, jj.z, jj.w};
-        double xj[4], yj[4], zj[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const double *rec = (const double *)(smem + o[q]);
-            xj[q] = rec[0];
-            yj[q] = rec[1];
-            if constexpr (D == 3) zj[q] = rec[2];
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            double dx = xj[q] - pi.x;
-            double dy = yj[q] - pi.y;
-            double d2 = dx * dx;
-            d2 = __builtin_fma(dy, dy, d2);
-            if constexpr (D == 3) {
-                double dz = zj[q] - pi.z;
-                d2 = __builtin_fma(dz, dz, d2);
-            }
-            if (d2 <= rin2) { // (the sentinel record is 1e100 away: padding never survives)
-                int ph = cnt & 3;
-                keep[0] = (ph == 0) ? o[q] : keep[0];
-                keep[1] = (ph == 1) ? o[q] : keep[1];
-                keep[2] = (ph == 2) ? o[q] : keep[2];
-                keep[3] = (ph == 3) ? o[q] : keep[3];
-                if (ph == 3) {
-                    out4[(size_t)(cnt >> 2) * 64] = make_ushort4((unsigned short)keep[0], (unsigned short)keep[1],
-                                                                  (unsigned short)keep[2], (unsigned short)keep[3]);
-                    keep[0] = keep[1] = keep[2] = keep[3] = sent;
-                }
-                ++cnt;
-            }
-        }
-    }
-    if (cnt & 3) { // partial last group, padded with the sentinel
-        out4[(size_t)(cnt >> 2) * 64] =
-            make_ushort4((unsigned short)keep[0], (unsigned short)keep[1], (unsigned short)keep[2], (unsigned short)keep[3]);
-    }
-    int mine = (cnt + 3) & ~3;
-    int mw = wave_max_i(mine);
-    for (int t = mine; t < mw; t += 4)
-        out4[(size_t)(t >> 2) * 64] = make_ushort4((unsigned short)sent, (unsigned short)sent, (unsigned short)sent, (unsigned short)sent);
-    if (lane == 0) nmax_in[wt] = mw;
-    // prune-time positions and the largest displacement since the build
-    double dd = 0.0;
-    if (active) {
-#pragma unroll
-        for (int c = 0; c < D; ++c) {
-            double xc = pos_get(pi, c);
-            s.x1[c][k] = xc;
-            double d = xc - s.x0[c][k];
-            dd = __builtin_fma(d, d, dd);
-        }
-    }
-    double wm = wave_max_d(dd);
-    if (lane == 0 && wm > 0.0) atomicMax(&sc->d1max2_bits, (unsigned long long)__double_as_longlong(wm));
-}
-
-// ------------------------------------------------------------------------------------------
 // The tiled force kernel: same arithmetic and summation order as k_force, neighbour
 // coordinates served from an LDS image of the tile's halo.  The image is an array of records
 // of RS bytes (x, y, z [, diameter]); row entries are the records' byte offsets, so a
@@ -851,12 +748,19 @@ __global__ void __launch_bounds__(MD_TILE)
 // A stride of 24 or 32 bytes spreads random 8-byte reads over all 64 banks.
 // Dynamic LDS: (H+1) * RS bytes.
 // ------------------------------------------------------------------------------------------
-template <int D, int POT, bool UNIFORM, bool WANT_UW, bool KICK>
+// PRUNE = true is the "prune step": the kernel walks the OUTER rows (cutoff + skin, valid for
+// ~25 steps) and, besides the forces, writes for every particle the INNER row -- the entries
+// within cutoff + inner skin right now, in the same order -- plus the reference positions x1 and
+// the largest displacement since the build.  The following steps run with PRUNE = false on the
+// inner rows, which are ~25 % shorter; since only sure misses are dropped and the order is kept,
+// every force evaluation is bit-identical to the unpruned one.
+template <int D, int POT, bool UNIFORM, bool WANT_UW, bool KICK, bool PRUNE>
 __global__ void __launch_bounds__(MD_TILE)
     k_force_tile(int n, DevState s, PotParams pp, const uint16_t *__restrict__ nlist16, int maxn,
                  const int32_t *__restrict__ nmax_tile, const uint32_t *__restrict__ halo, int hcap,
                  const int32_t *__restrict__ halo_count, double dt, double *__restrict__ partials, int nblk_total,
-                 const Scalars *__restrict__ sc, int step)
+                 Scalars *__restrict__ sc, int step, uint16_t *__restrict__ rows_in, int32_t *__restrict__ nmax_in,
+                 double rin2)
 {
     constexpr int RS = UNIFORM ? 24 : 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -881,12 +785,12 @@ __global__ void __launch_bounds__(MD_TILE)
     int lane = threadIdx.x & 63;
     int wt = bid * (MD_TILE / 64) + (threadIdx.x >> 6);
     const ushort4 *row4 = (const ushort4 *)(nlist16 + ((size_t)wt * maxn) * 64) + lane;
+    uint16_t *rin = PRUNE ? rows_in + ((size_t)wt * maxn) * 64 : nullptr;
+    int cin = 0;
     int m = nmax_tile[wt];
     double4 pi = P[kk];
     double fx = 0.0, fy = 0.0, fz = 0.0, us = 0.0, ws = 0.0;
-    // the row indices of group g+1 are fetched while group g is computed: issued at the top of
-    // the loop and consumed one iteration later, so their memory latency hides under the
-    // pair arithmetic instead of stalling every iteration (vmcnt(0) right after the load)
+    // the row indices of group g+1 are fetched while group g is computed
     ushort4 jnext = row4[0];
     for (int r = 0; r < m; r += 4) {
         ushort4 jj = jnext;
@@ -913,6 +817,12 @@ __global__ void __launch_bounds__(MD_TILE)
                 dz = zj[q] - pi.z;
                 d2 = __builtin_fma(dz, dz, d2);
             }
+            if constexpr (PRUNE) {
+                if (d2 <= rin2) { // (padding entries are 1e100 away: they never survive)
+                    rin[row_off(cin, lane)] = (uint16_t)o[q];
+                    ++cin;
+                }
+            }
             bool hit = d2 < pp.c2;
             double d2m = mask_d2(d2, hit);
             double u = 0.0, fpr;
@@ -925,6 +835,26 @@ __global__ void __launch_bounds__(MD_TILE)
                 ws = __builtin_fma(fpr, hit ? d2 : 0.0, ws);
             }
         }
+    }
+    if constexpr (PRUNE) {
+        // pad the inner row to the wave's longest (a multiple of 4) with the sentinel record
+        const uint16_t sent = (uint16_t)(H * RS);
+        int mw = wave_max_i((cin + 3) & ~3);
+        for (int t = cin; t < mw; ++t) rin[row_off(t, lane)] = sent;
+        if (lane == 0) nmax_in[wt] = mw;
+        // reference positions of the inner rows, largest displacement since the build
+        double dd = 0.0;
+        if (active) {
+#pragma unroll
+            for (int c = 0; c < D; ++c) {
+                double xc = pos_get(pi, c);
+                s.x1[c][k] = xc;
+                double d = xc - s.x0[c][k];
+                dd = __builtin_fma(d, d, dd);
+            }
+        }
+        double wm = wave_max_d(dd);
+        if (lane == 0 && wm > 0.0) atomicMax(&sc->d1max2_bits, (unsigned long long)__double_as_longlong(wm));
     }
     double ke = 0.0;
     if (active) {
@@ -969,14 +899,15 @@ __global__ void __launch_bounds__(MD_TILE)
 // ------------------------------------------------------------------------------------------
 template <int D, bool SCALE>
 __global__ void __launch_bounds__(MD_BLOCK)
-    k_kickdrift(int n, DevState s, double dt, double skin_half, double inner_half, Scalars *sc, int step)
+    k_kickdrift(int n, DevState s, double dt, double skin_half, double inner_half, int use_d1, Scalars *sc, int step)
 {
     if (sc->first_viol < step) return;
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     // The rows the force kernel walks were pruned at x1 with margin 2*inner_half, the outer rows
     // built at x0 with margin 2*skin_half, and no particle had moved more than d1 between the two:
     // both stay valid while every particle is within min(inner_half, skin_half - d1) of x1.
-    double d1 = sqrt(__longlong_as_double((long long)sc->d1max2_bits));
+    // (Without inner rows: x1 == x0, d1 = 0, inner_half = skin_half.)
+    double d1 = use_d1 ? sqrt(__longlong_as_double((long long)sc->d1max2_bits)) : 0.0;
     double thr = fmin(inner_half, skin_half - d1);
     double thr2 = thr > 0.0 ? thr * thr : -1.0;
     double disp2 = 0.0;

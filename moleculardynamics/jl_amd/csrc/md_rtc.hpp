@@ -54,7 +54,7 @@ inline RtcModule *rtc_build(const char *user_src, const char *entry)
         for (int uw = 0; uw < 2; ++uw)
             for (int kk = 0; kk < 2; ++kk) {
                 char b[160];
-                snprintf(b, sizeof b, "k_force_tile<%d, %d, false, %s, %s>", d, POT_CUSTOM, uw ? "true" : "false", kk ? "true" : "false");
+                snprintf(b, sizeof b, "k_force_tile<%d, %d, false, %s, %s, false>", d, POT_CUSTOM, uw ? "true" : "false", kk ? "true" : "false");
                 names.push_back(b);
                 snprintf(b, sizeof b, "k_force<%d, %d, false, %s, %s>", d, POT_CUSTOM, uw ? "true" : "false", kk ? "true" : "false");
                 names.push_back(b);

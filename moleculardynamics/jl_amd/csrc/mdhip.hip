@@ -150,7 +150,8 @@ struct md_ctx {
     // dynamic pruning of the rows (single-GPU handles with a skin): inner rows used by the force kernel
     double inner_skin_req = 0.0; // off by default: the prune kernel's compaction currently costs more than it saves
     double inner_skin = 0.0;
-    bool inner_valid = false;
+    bool inner_valid = false; // the inner rows exist and the force kernel uses them
+    bool prune_on = false;    // this build supports inner rows (tiled path, skin > inner skin > 0, single GPU)
     DBuf<double> x1[3];
     DBuf<uint16_t> nlist16_in;
     DBuf<int32_t> nmax_tile_in;
@@ -218,12 +219,8 @@ __global__ void k_reset_flags(Scalars *sc)
     sc->d1max2_bits = 0ull;
 }
 
-// before a prune: the displacement maximum is recomputed, and a recorded violation is consumed
-__global__ void k_reset_d1(Scalars *sc)
-{
-    sc->d1max2_bits = 0ull;
-    sc->first_viol = MD_NO_VIOLATION;
-}
+// before a prune step: the displacement maximum since the build is recomputed by that step
+__global__ void k_reset_d1(Scalars *sc) { sc->d1max2_bits = 0ull; }
 
 void alloc_state(md_ctx *c, int which, int64_t cap)
 {
@@ -371,7 +368,6 @@ void ensure_capacity(md_ctx *c, int64_t need_next)
     c->newslot.ensure(newcap + 1);
 }
 
-void launch_prune(md_ctx *c);
 void launch_ghost_update(md_ctx *c, int step);
 
 template <int D>
@@ -527,15 +523,14 @@ void rebuild_t(md_ctx *c)
     c->list_valid = true;
     c->steps_since_build = 0;
     c->st_rebuilds++;
-    c->inner_valid = false;
-    bool prune_on = c->use_tiles && !c->dom.on && c->skin > 0.0 && c->inner_skin_req > 0.0 &&
-                    c->inner_skin_req < 0.9 * c->skin;
-    if (prune_on) {
+    c->inner_valid = false; // the next force evaluation is a prune step
+    c->prune_on = c->use_tiles && !c->dom.on && c->skin > 0.0 && c->inner_skin_req > 0.0 &&
+                  c->inner_skin_req < 0.9 * c->skin && c->pot_kind != POT_CUSTOM;
+    if (c->prune_on) {
         c->inner_skin = c->inner_skin_req;
         for (int d = 0; d < c->dim; ++d) c->x1[d].ensure(c->ncap);
         c->nlist16_in.ensure((size_t)c->ntiles * c->maxn * 64);
         c->nmax_tile_in.ensure(c->ntiles);
-        launch_prune(c);
     }
 }
 
@@ -580,43 +575,57 @@ void prof_collect(md_ctx *c)
     c->prof_used = 0;
 }
 
+// rows: 0 = whatever is current (inner rows when valid; a prune step when they are due),
+//       1 = outer rows, no pruning (md_compute_forces and friends)
 template <int D, int POT, bool UNIFORM>
-void launch_force_tpu(md_ctx *c, bool want_uw, bool kick, double dt, int step)
+void launch_force_tpu(md_ctx *c, bool want_uw, bool kick, double dt, int step, int rows)
 {
-    const uint16_t *rows16 = c->inner_valid ? c->nlist16_in.p : c->nlist16.p;
-    const int32_t *rowmax = c->inner_valid ? c->nmax_tile_in.p : c->nmax_tile.p;
     int n = (int)c->n;
-    DevState s = c->dev(c->cur);
     int nb = c->nblk;
+    bool prune_step = rows == 0 && c->prune_on && !c->inner_valid && kick;
+    bool use_inner = rows == 0 && c->inner_valid;
+    const uint16_t *rows16 = use_inner ? c->nlist16_in.p : c->nlist16.p;
+    const int32_t *rowmax = use_inner ? c->nmax_tile_in.p : c->nmax_tile.p;
+    DevState s = c->dev(c->cur);
+    double rin = c->rc + c->inner_skin;
+    if (prune_step) {
+        for (int d = 0; d < 3; ++d) s.x1[d] = c->x1[d].p; // the prune step writes the new reference positions
+        k_reset_d1<<<1, 1, 0, c->stream>>>(c->scal.p);
+    }
 #define LF(UW, KK)                                                                                                  \
     k_force<D, POT, UNIFORM, UW, KK><<<nb, MD_BLOCK, 0, c->stream>>>(n, s, c->pp, c->nlist.p, c->maxn,              \
                                                                      c->nmax_tile.p, dt, c->partials.p, nb,         \
                                                                      c->scal.p, step)
-#define LT(UW, KK)                                                                                                  \
+#define LT(UW, KK, PR)                                                                                              \
     do {                                                                                                            \
         static size_t attr_bytes = 0;                                                                               \
-        auto kfn = k_force_tile<D, POT, UNIFORM, UW, KK>;                                                           \
+        auto kfn = k_force_tile<D, POT, UNIFORM, UW, KK, PR>;                                                       \
         if (c->tile_lds > attr_bytes) {                                                                             \
             HIPCHK(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,               \
                                        (int)(160 * 1024 - 256)));                                                   \
             attr_bytes = 160 * 1024;                                                                                \
         }                                                                                                           \
-        kfn<<<nb, MD_TILE, c->tile_lds, c->stream>>>(n, s, c->pp, rows16, c->maxn, rowmax, c->halo.p,              \
-                                                     c->hcap, c->halo_count.p, dt, c->partials.p, nb, c->scal.p,    \
-                                                     step);                                                         \
+        kfn<<<nb, MD_TILE, c->tile_lds, c->stream>>>(n, s, c->pp, rows16, c->maxn, rowmax, c->halo.p, c->hcap,      \
+                                                     c->halo_count.p, dt, c->partials.p, nb, c->scal.p, step,       \
+                                                     c->nlist16_in.p, c->nmax_tile_in.p, rin * rin);                \
     } while (0)
     prof_begin(c);
     if (c->use_tiles) {
-        if (want_uw) {
-            if (kick)
-                LT(true, true);
+        if (prune_step) {
+            if (want_uw)
+                LT(true, true, true);
             else
-                LT(true, false);
+                LT(false, true, true);
+        } else if (want_uw) {
+            if (kick)
+                LT(true, true, false);
+            else
+                LT(true, false, false);
         } else {
             if (kick)
-                LT(false, true);
+                LT(false, true, false);
             else
-                LT(false, false);
+                LT(false, false, false);
         }
     } else if (want_uw) {
         if (kick)
@@ -632,6 +641,11 @@ void launch_force_tpu(md_ctx *c, bool want_uw, bool kick, double dt, int step)
     prof_end(c);
 #undef LF
 #undef LT
+    if (prune_step) {
+        c->inner_valid = true;
+        c->steps_since_prune = 0;
+        c->st_prunes++;
+    }
 }
 
 // user potential: the same two kernels, compiled at run time around the user's evaluate()
@@ -643,15 +657,19 @@ void launch_force_custom(md_ctx *c, int dim, bool want_uw, bool kick, double dt,
     int nb = c->nblk;
     prof_begin(c);
     if (c->use_tiles && c->tile_lds <= 64 * 1024) {
-        const uint16_t *l16 = c->inner_valid ? c->nlist16_in.p : c->nlist16.p;
+        // (user potentials always run on the outer rows: no prune-step variant is compiled for them)
+        const uint16_t *l16 = c->nlist16.p;
         int maxn = c->maxn;
-        const int32_t *nmt = c->inner_valid ? c->nmax_tile_in.p : c->nmax_tile.p;
+        const int32_t *nmt = c->nmax_tile.p;
         const uint32_t *halo = c->halo.p;
         int hcap = c->hcap;
         const int32_t *hc = c->halo_count.p;
         double *part = c->partials.p;
-        const Scalars *sc = c->scal.p;
-        void *args[] = {&n, &s, &c->pp, &l16, &maxn, &nmt, &halo, &hcap, &hc, &dt, &part, &nb, &sc, &step};
+        Scalars *sc = c->scal.p;
+        uint16_t *rin = nullptr;
+        int32_t *nin = nullptr;
+        double rin2 = 0.0;
+        void *args[] = {&n, &s, &c->pp, &l16, &maxn, &nmt, &halo, &hcap, &hc, &dt, &part, &nb, &sc, &step, &rin, &nin, &rin2};
         HIPCHK(hipModuleLaunchKernel(c->rtc->tile[dim - 2][want_uw][kick], nb, 1, 1, MD_TILE, 1, 1,
                                      (unsigned)c->tile_lds, c->stream, args, nullptr));
     } else {
@@ -669,24 +687,24 @@ void launch_force_custom(md_ctx *c, int dim, bool want_uw, bool kick, double dt,
 }
 
 template <int D>
-void launch_force_d(md_ctx *c, bool want_uw, bool kick, double dt, int step)
+void launch_force_d(md_ctx *c, bool want_uw, bool kick, double dt, int step, int rows)
 {
     bool u = c->uniform_sigma;
     switch (c->pot_kind) {
     case POT_LJ:
         if (u)
-            launch_force_tpu<D, POT_LJ, true>(c, want_uw, kick, dt, step);
+            launch_force_tpu<D, POT_LJ, true>(c, want_uw, kick, dt, step, rows);
         else
-            launch_force_tpu<D, POT_LJ, false>(c, want_uw, kick, dt, step);
+            launch_force_tpu<D, POT_LJ, false>(c, want_uw, kick, dt, step, rows);
         break;
     case POT_PSEUDOHS:
         if (u)
-            launch_force_tpu<D, POT_PSEUDOHS, true>(c, want_uw, kick, dt, step);
+            launch_force_tpu<D, POT_PSEUDOHS, true>(c, want_uw, kick, dt, step, rows);
         else
-            launch_force_tpu<D, POT_PSEUDOHS, false>(c, want_uw, kick, dt, step);
+            launch_force_tpu<D, POT_PSEUDOHS, false>(c, want_uw, kick, dt, step, rows);
         break;
     case POT_POLYDISPERSE:
-        launch_force_tpu<D, POT_POLYDISPERSE, false>(c, want_uw, kick, dt, step);
+        launch_force_tpu<D, POT_POLYDISPERSE, false>(c, want_uw, kick, dt, step, rows);
         break;
     case POT_CUSTOM:
         launch_force_custom(c, D, want_uw, kick, dt, step);
@@ -696,12 +714,12 @@ void launch_force_d(md_ctx *c, bool want_uw, bool kick, double dt, int step)
     }
 }
 
-void launch_force(md_ctx *c, bool want_uw, bool kick, double dt, int step)
+void launch_force(md_ctx *c, bool want_uw, bool kick, double dt, int step, int rows = 0)
 {
     if (c->dim == 3)
-        launch_force_d<3>(c, want_uw, kick, dt, step);
+        launch_force_d<3>(c, want_uw, kick, dt, step, rows);
     else
-        launch_force_d<2>(c, want_uw, kick, dt, step);
+        launch_force_d<2>(c, want_uw, kick, dt, step, rows);
 }
 
 void launch_kickdrift(md_ctx *c, bool nvt, double dt, bool check, int step)
@@ -712,59 +730,18 @@ void launch_kickdrift(md_ctx *c, bool nvt, double dt, bool check, int step)
     // displacement limits (see k_kickdrift); INFINITY disables the check (rebuild-every-step mode)
     double skin_half = check ? 0.5 * c->skin : INFINITY;
     double inner_half = check ? (c->inner_valid ? 0.5 * c->inner_skin : 0.5 * c->skin) : INFINITY;
+    int use_d1 = c->inner_valid ? 1 : 0;
     if (c->dim == 3) {
         if (nvt)
-            k_kickdrift<3, true><<<nb, MD_BLOCK, 0, c->stream>>>(n, s, dt, skin_half, inner_half, c->scal.p, step);
+            k_kickdrift<3, true><<<nb, MD_BLOCK, 0, c->stream>>>(n, s, dt, skin_half, inner_half, use_d1, c->scal.p, step);
         else
-            k_kickdrift<3, false><<<nb, MD_BLOCK, 0, c->stream>>>(n, s, dt, skin_half, inner_half, c->scal.p, step);
+            k_kickdrift<3, false><<<nb, MD_BLOCK, 0, c->stream>>>(n, s, dt, skin_half, inner_half, use_d1, c->scal.p, step);
     } else {
         if (nvt)
-            k_kickdrift<2, true><<<nb, MD_BLOCK, 0, c->stream>>>(n, s, dt, skin_half, inner_half, c->scal.p, step);
+            k_kickdrift<2, true><<<nb, MD_BLOCK, 0, c->stream>>>(n, s, dt, skin_half, inner_half, use_d1, c->scal.p, step);
         else
-            k_kickdrift<2, false><<<nb, MD_BLOCK, 0, c->stream>>>(n, s, dt, skin_half, inner_half, c->scal.p, step);
+            k_kickdrift<2, false><<<nb, MD_BLOCK, 0, c->stream>>>(n, s, dt, skin_half, inner_half, use_d1, c->scal.p, step);
     }
-}
-
-template <int D, bool UNIFORM>
-void launch_prune_t(md_ctx *c)
-{
-    static size_t attr_bytes = 0;
-    auto kfn = k_prune<D, UNIFORM>;
-    if (c->tile_lds > attr_bytes) {
-        HIPCHK(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - 256)));
-        attr_bytes = 160 * 1024;
-    }
-    double rin = c->rc + c->inner_skin;
-    DevState s = c->dev(c->cur);
-    for (int d = 0; d < 3; ++d) s.x1[d] = c->x1[d].p; // the prune writes the new reference positions
-    k_reset_d1<<<1, 1, 0, c->stream>>>(c->scal.p);
-    // after a displacement violation the step's ghost refresh was skipped along with its force half:
-    // bring the ghost copies up to the owners' current positions before measuring distances
-    launch_ghost_update(c, -1);
-    kfn<<<c->nblk, MD_TILE, c->tile_lds, c->stream>>>((int)c->n, s, rin * rin, c->nlist16.p, c->nlist16_in.p, c->maxn,
-                                                      c->nmax_tile.p, c->nmax_tile_in.p, c->halo.p, c->hcap,
-                                                      c->halo_count.p, c->scal.p);
-}
-
-// refresh the inner rows from the outer ones at the current positions
-void launch_prune(md_ctx *c)
-{
-    bool uniform_kernel = c->tile_rs == 24;
-    if (c->dim == 3) {
-        if (uniform_kernel)
-            launch_prune_t<3, true>(c);
-        else
-            launch_prune_t<3, false>(c);
-    } else {
-        if (uniform_kernel)
-            launch_prune_t<2, true>(c);
-        else
-            launch_prune_t<2, false>(c);
-    }
-    HIPCHK(hipGetLastError());
-    c->inner_valid = true;
-    c->steps_since_prune = 0;
-    c->st_prunes++;
 }
 
 void launch_ghost_update(md_ctx *c, int step)
@@ -1123,8 +1100,7 @@ int md_compute_forces(md_ctx *ctx, double *energy, double *virial)
 {
     API_BEGIN
     if (!ctx->list_valid) rebuild(ctx);
-    launch_force(ctx, true, false, 0.0, -1); // (inner rows, if any, were pruned at these very positions or are
-                                             //  still valid: md_run keeps them so)
+    launch_force(ctx, true, false, 0.0, -1, 1); // outer rows: always valid for the current positions
     launch_finalize(ctx, true, false, 1.0, 0.0, -1);
     HIPCHK(hipGetLastError());
     Scalars h = read_scalars(ctx);
@@ -1213,18 +1189,25 @@ int md_run(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, double tau, dou
         // later kernel of the chunk skips itself.  With pruning on, the rows in use are the inner
         // rows: refreshing them is a cheap prune; the outer rows are rebuilt only when the
         // displacement accumulated since the build (d1, measured by the prune) nears skin/2.
-        auto refresh = [&](double d1) {
-            bool pruning = ctx->inner_valid;
+        // refresh: either rebuild the outer rows, or just mark the inner rows stale so that the next
+        // force evaluation is a prune step.  Returns true if it rebuilt (ghosts are then fresh).
+        auto refresh = [&](double d1) -> bool {
             // the next prune interval may add up to inner_skin/2 (+ a step of overshoot) to d1
-            bool need_build = !pruning || (d1 + 0.75 * ctx->inner_skin >= 0.5 * ctx->skin);
-            if (need_build)
-                rebuild(ctx); // (prunes right after when pruning is on)
-            else
-                launch_prune(ctx);
+            bool need_build = !ctx->prune_on || (d1 + 0.75 * ctx->inner_skin >= 0.5 * ctx->skin);
+            if (need_build) {
+                rebuild(ctx);
+                return true;
+            }
+            ctx->inner_valid = false;
+            return false;
         };
         int s = 0;
         while (s < (int)nsteps) {
-            bool pruning = ctx->inner_valid;
+            bool pruning = ctx->prune_on;
+            // if the inner rows are stale, the chunk's first force evaluation is a prune step and its drift
+            // is checked against the OUTER rows' validity
+            bool starts_with_prune = ctx->prune_on && !ctx->inner_valid;
+            if (starts_with_prune) ctx->steps_since_prune = 0;
             int64_t target = pruning ? ctx->prune_target : ctx->target_interval;
             int64_t since = pruning ? ctx->steps_since_prune : ctx->steps_since_build;
             int64_t room = std::max<int64_t>(1, target - since);
@@ -1256,7 +1239,21 @@ int md_run(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, double tau, dou
                 else
                     ctx->target_interval = nt;
                 ctx->steps_since_build += (m - s) + 1;
-                refresh(d1);
+                bool rebuilt;
+                if (starts_with_prune && m == s) {
+                    // the violated criterion was the outer rows' (the prune step itself was skipped, its d1
+                    // is meaningless): only a rebuild helps
+                    rebuild(ctx);
+                    rebuilt = true;
+                } else {
+                    rebuilt = refresh(d1);
+                }
+                if (!rebuilt) {
+                    // a prune step follows: consume the recorded violation, and redo the ghost refresh that
+                    // was skipped along with the step's force half
+                    k_reset_viol<<<1, 1, 0, st>>>(ctx->scal.p);
+                    launch_ghost_update(ctx, -1);
+                }
                 force_part(m);
                 s = m + 1;
             } else {
