@@ -659,6 +659,7 @@ __global__ void __launch_bounds__(MD_BLOCK)
 // halo order, which only decides where a record sits in LDS -- never the order of a sum.
 // ------------------------------------------------------------------------------------------
 #define MD_TILE 256
+#define MD_UNROLL 8
 #define MD_HT 16384 // hash slots (load factor < 0.4 at the halo sizes above)
 #define MD_HT_BITS 14
 #define MD_EMPTY 0xffffffffu
@@ -790,16 +791,33 @@ __global__ void __launch_bounds__(MD_TILE)
     int m = nmax_tile[wt];
     double4 pi = P[kk];
     double fx = 0.0, fy = 0.0, fz = 0.0, us = 0.0, ws = 0.0;
-    // the row indices of group g+1 are fetched while group g is computed
-    ushort4 jnext = row4[0];
-    for (int r = 0; r < m; r += 4) {
-        ushort4 jj = jnext;
-        int rn = (r + 4 < m) ? r + 4 : r;
-        jnext = row4[(size_t)(rn >> 2) * 64];
-        unsigned o[4] = {jj.x, jj.y, jj.z, jj.w};
-        double xj[4], yj[4], zj[4], wj[4];
+    // Two index groups (8 candidates) per iteration: all their LDS reads are issued before the first
+    // use, which is what hides the LDS latency at 4 waves per SIMD.  The indices of the next pair of
+    // groups are fetched while this one is computed.  A row has a multiple of 4 entries; when the
+    // second group of the last pair does not exist its offsets are replaced by the sentinel record.
+    const unsigned sent_off = (unsigned)H * RS;
+    constexpr int G = MD_UNROLL / 4; // index groups per iteration
+    ushort4 jn[G];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+    for (int g = 0; g < G; ++g) jn[g] = row4[(size_t)((4 * g < m) ? g : 0) * 64];
+    for (int r = 0; r < m; r += MD_UNROLL) {
+        unsigned o[MD_UNROLL];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            bool has = r + 4 * g < m;
+            o[4 * g + 0] = has ? jn[g].x : sent_off;
+            o[4 * g + 1] = has ? jn[g].y : sent_off;
+            o[4 * g + 2] = has ? jn[g].z : sent_off;
+            o[4 * g + 3] = has ? jn[g].w : sent_off;
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            int rg = r + MD_UNROLL + 4 * g;
+            jn[g] = row4[(size_t)(((rg < m) ? rg : 0) >> 2) * 64];
+        }
+        double xj[MD_UNROLL], yj[MD_UNROLL], zj[MD_UNROLL], wj[MD_UNROLL];
+#pragma unroll
+        for (int q = 0; q < MD_UNROLL; ++q) {
             const double *rec = (const double *)(smem + o[q]);
             xj[q] = rec[0];
             yj[q] = rec[1];
@@ -807,7 +825,7 @@ __global__ void __launch_bounds__(MD_TILE)
             if constexpr (!UNIFORM) wj[q] = rec[3];
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < MD_UNROLL; ++q) {
             double dx = xj[q] - pi.x;
             double dy = yj[q] - pi.y;
             double d2 = dx * dx;
