@@ -68,8 +68,7 @@ int md_set_skin(md_ctx *ctx, double skin);
 
 /* Dynamic pruning of the rows: every few steps the rows the force kernel walks are refreshed from
  * the Verlet rows, keeping the entries within list_cutoff + inner_skin at that moment.  Results are
- * unchanged (only sure misses are dropped, order kept); inner_skin = 0 turns it off (the default:
- * at N = 2^20 the prune pass still costs more than the shorter rows save). */
+ * unchanged (only sure misses are dropped, order kept); inner_skin = 0 turns it off.  Default 0.10. */
 int md_set_inner_skin(md_ctx *ctx, double inner_skin);
 
 /* State transfer; any pointer may be NULL (= leave that array as it is on the device).
@@ -154,6 +153,11 @@ int md_dom_migrate_unpack(md_ctx *ctx, const int64_t *nrecv /* [2] */);
 int md_dom_halo_pack(md_ctx *ctx, int64_t *nsend /* [2] */);
 int md_dom_halo_unpack(md_ctx *ctx, const int64_t *nrecv /* [2] */);
 int md_dom_build(md_ctx *ctx);
+/* Optional zero-copy exchange: device buffers owned by the caller (e.g. torch tensors) that the
+ * per-step halo coordinates are packed into / read from directly, instead of the library's own
+ * buffers + md_dom_get_sendbuf / md_dom_put_recvbuf.  Each must hold capacity_doubles doubles. */
+int md_dom_set_step_buffers(md_ctx *ctx, void *send_left, void *send_right, void *recv_left, void *recv_right,
+                            int64_t capacity_doubles);
 int md_dom_get_sendbuf(md_ctx *ctx, int side, int64_t ndoubles, void *dst, int dst_is_device);
 int md_dom_put_recvbuf(md_ctx *ctx, int side, int64_t ndoubles, const void *src, int src_is_device);
 /* first half of a step (pending Bussi rescale, half-kick, drift; src/integrate.jl:8-21); *violated = 1 if

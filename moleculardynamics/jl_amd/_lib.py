@@ -20,7 +20,7 @@ EXPORTS = [
     "md_scale_velocities", "md_profile", "md_get_stats", "md_version",
     "md_create_domain", "md_dom_set_uniform", "md_dom_upload", "md_dom_download", "md_dom_migrate_pack",
     "md_dom_migrate_unpack", "md_dom_halo_pack", "md_dom_halo_unpack", "md_dom_build", "md_dom_get_sendbuf",
-    "md_dom_put_recvbuf", "md_dom_step_begin", "md_dom_step_end", "md_dom_forces", "md_dom_set_scale",
+    "md_dom_put_recvbuf", "md_dom_set_step_buffers", "md_dom_step_begin", "md_dom_step_end", "md_dom_forces", "md_dom_set_scale",
     "md_dom_counts",
 ]
 
@@ -96,6 +96,7 @@ def load():
     L.md_dom_build.argtypes = [vp]
     L.md_dom_get_sendbuf.argtypes = [vp, C.c_int, C.c_int64, C.c_void_p, C.c_int]
     L.md_dom_put_recvbuf.argtypes = [vp, C.c_int, C.c_int64, C.c_void_p, C.c_int]
+    L.md_dom_set_step_buffers.argtypes = [vp, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
     L.md_dom_step_begin.argtypes = [vp, C.c_double, C.POINTER(C.c_int)]
     L.md_dom_step_end.argtypes = [vp, C.c_double, C.c_int, dp]
     L.md_dom_forces.argtypes = [vp, C.c_double, C.c_int, C.c_int, dp]

@@ -114,6 +114,17 @@ class Exchanger:
             dev_rr.copy_(recv_right)
             self.torch.cuda.synchronize()
 
+    def allreduce_async(self, values, op="sum"):
+        """Start an all-reduce; returns a function that waits and yields the first reduced value."""
+        t = self.torch.tensor(values, dtype=self.torch.float64, device=self.coll_device)
+        w = self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM if op == "sum" else self.dist.ReduceOp.MAX,
+                                 group=self.group, async_op=True)
+
+        def wait():
+            w.wait()
+            return float(t[0].item())
+        return wait
+
     def allreduce(self, values, op="sum"):
         t = self.torch.tensor(values, dtype=self.torch.float64, device=self.coll_device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM if op == "sum" else self.dist.ReduceOp.MAX,
@@ -276,9 +287,29 @@ class DomainDevice:
         self._chk(self._L.md_dom_put_recvbuf(self._h, 1, nrecv[1] * rec, rr.data_ptr(), dev))
         return nrecv
 
-    def _exchange_fixed(self, nsend, nrecv, rec):
-        """Per-step exchange: the counts were fixed at the build."""
+    def _bind_step_buffers(self):
+        """After a build: (re)bind caller-owned device buffers for the per-step halo coordinates so that the
+        library packs/unpacks them in place (no staging copies, no extra synchronisations)."""
         ex = self.ex
+        self._zero_copy = False
+        if not ex.on_device:
+            return
+        need = 3 * max(max(self._nsend_halo), max(self._nrecv_halo), 1)
+        cap = max(int(need * 1.5), 4096)
+        bufs = [ex.buffer(nm, cap) for nm in ("zsl", "zsr", "zrl", "zrr")]
+        cap = min(b.numel() for b in bufs)
+        self._chk(self._L.md_dom_set_step_buffers(self._h, *(b.data_ptr() for b in bufs), cap))
+        self._zbufs = bufs
+        self._zero_copy = True
+
+    def _exchange_fixed(self, nsend, nrecv, rec, overlap=None):
+        """Per-step exchange: the counts were fixed at the build.  `overlap` is called between posting and
+        completing the transfers (used for the violation-flag all-reduce)."""
+        ex = self.ex
+        if getattr(self, "_zero_copy", False):
+            sl, sr, rl, rr = self._zbufs
+            ex.sendrecv(sl[: nsend[0] * rec], sr[: nsend[1] * rec], rl[: nrecv[0] * rec], rr[: nrecv[1] * rec])
+            return
         dev = 1 if ex.on_device else 0
         sl = ex.buffer("sl", nsend[0] * rec)[: nsend[0] * rec]
         sr = ex.buffer("sr", nsend[1] * rec)[: nsend[1] * rec]
@@ -301,6 +332,7 @@ class DomainDevice:
         self._nrecv_halo = self._exchange(self._nsend_halo, HALO_REC)
         self._chk(self._L.md_dom_halo_unpack(self._h, (C.c_int64 * 2)(*self._nrecv_halo)))
         self._chk(self._L.md_dom_build(self._h))
+        self._bind_step_buffers()
         self.steps_since_build = 0
         self.builds += 1
 
@@ -327,7 +359,11 @@ class DomainDevice:
         for s in range(nsteps):
             last = s == nsteps - 1
             self._chk(self._L.md_dom_step_begin(self._h, float(dt), C.byref(viol)))
-            any_viol = self.ex.allreduce([float(viol.value)], op="max")[0] > 0.0
+            # the violation flag is all-reduced while the halo coordinates travel (the exchange is harmless if
+            # a rebuild follows: the build re-sends everything)
+            work = self.ex.allreduce_async([float(viol.value)], op="max")
+            self._exchange_fixed(self._nsend_halo, self._nrecv_halo, POS_REC)
+            any_viol = work() > 0.0
             if any_viol:
                 # some particle somewhere moved skin/2: every rank rebuilds at the drifted positions
                 self.violations += 1
@@ -336,7 +372,6 @@ class DomainDevice:
                 self.build()
                 self._chk(self._L.md_dom_forces(self._h, float(dt), 1, 1 if last else 0, uwk))
             else:
-                self._exchange_fixed(self._nsend_halo, self._nrecv_halo, POS_REC)
                 self._chk(self._L.md_dom_step_end(self._h, float(dt), 1 if last else 0, uwk))
                 self.steps_since_build += 1
             if nvt or last:
