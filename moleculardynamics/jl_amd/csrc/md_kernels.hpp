@@ -786,7 +786,8 @@ __global__ void __launch_bounds__(MD_TILE)
     int lane = threadIdx.x & 63;
     int wt = bid * (MD_TILE / 64) + (threadIdx.x >> 6);
     const ushort4 *row4 = (const ushort4 *)(nlist16 + ((size_t)wt * maxn) * 64) + lane;
-    uint16_t *rin = PRUNE ? rows_in + ((size_t)wt * maxn) * 64 : nullptr;
+    unsigned long long *rin64 = PRUNE ? (unsigned long long *)(rows_in + ((size_t)wt * maxn) * 64) + lane : nullptr;
+    unsigned long long acc = 0ull;
     int cin = 0;
     int m = nmax_tile[wt];
     double4 pi = P[kk];
@@ -837,8 +838,13 @@ __global__ void __launch_bounds__(MD_TILE)
             }
             if constexpr (PRUNE) {
                 if (d2 <= rin2) { // (padding entries are 1e100 away: they never survive)
-                    rin[row_off(cin, lane)] = (uint16_t)o[q];
+                    // four 16-bit entries of a row are one 8-byte word (row_off): write it when it is full
+                    acc |= (unsigned long long)o[q] << (16 * (cin & 3));
                     ++cin;
+                    if ((cin & 3) == 0) {
+                        rin64[(size_t)((cin >> 2) - 1) * 64] = acc;
+                        acc = 0ull;
+                    }
                 }
             }
             bool hit = d2 < pp.c2;
@@ -856,9 +862,16 @@ __global__ void __launch_bounds__(MD_TILE)
     }
     if constexpr (PRUNE) {
         // pad the inner row to the wave's longest (a multiple of 4) with the sentinel record
-        const uint16_t sent = (uint16_t)(H * RS);
+        const unsigned long long sent = (unsigned long long)(H * RS);
+        const unsigned long long sent4 = sent | (sent << 16) | (sent << 32) | (sent << 48);
         int mw = wave_max_i((cin + 3) & ~3);
-        for (int t = cin; t < mw; ++t) rin[row_off(t, lane)] = sent;
+        int g = cin >> 2;
+        if (cin & 3) {
+            int sh = 16 * (cin & 3);
+            rin64[(size_t)g * 64] = acc | (sent4 << sh);
+            ++g;
+        }
+        for (; g < (mw >> 2); ++g) rin64[(size_t)g * 64] = sent4;
         if (lane == 0) nmax_in[wt] = mw;
         // reference positions of the inner rows, largest displacement since the build
         double dd = 0.0;
@@ -949,6 +962,29 @@ __global__ void __launch_bounds__(MD_BLOCK)
     // one atomic per violating wave only (a same-address atomic from every wave serialises)
     if (__any(disp2 > thr2)) {
         if ((threadIdx.x & 63) == 0) atomicMin(&sc->first_viol, step);
+    }
+}
+
+// Largest displacement since the list build, max_i |x_i - x0_i|^2 (as double bits in sc->max_disp2_bits, which
+// the caller zeroes first).  Run after an inner-row violation to decide rigorously between a prune of the inner
+// rows (outer rows still valid: <= (skin/2)^2) and a rebuild.
+template <int D>
+__global__ void __launch_bounds__(MD_BLOCK) k_max_disp0(int n, DevState s, Scalars *sc)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    double dd = 0.0;
+    if (k < n) {
+        double4 p = s.pos[k];
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            double d = pos_get(p, c) - s.x0[c][k];
+            dd = __builtin_fma(d, d, dd);
+        }
+    }
+    double wm = wave_max_d(dd);
+    if ((threadIdx.x & 63) == 0) {
+        unsigned long long bits = (unsigned long long)__double_as_longlong(wm);
+        if (bits > sc->max_disp2_bits) atomicMax(&sc->max_disp2_bits, bits);
     }
 }
 

@@ -158,7 +158,9 @@ struct md_ctx {
     DBuf<uint16_t> nlist16_in;
     DBuf<int32_t> nmax_tile_in;
     int64_t steps_since_prune = 0;
-    int64_t prune_target = 6;
+    double d1_rate = 0.0;       // growth per step of the largest displacement since a reference (measured)
+    bool rate_known = false;
+    double safety = 0.97;       // fraction of the validity radii the plan uses
     int64_t st_prunes = 0;
 
     // stats / profiling
@@ -221,8 +223,15 @@ __global__ void k_reset_flags(Scalars *sc)
     sc->d1max2_bits = 0ull;
 }
 
+__global__ void k_reset_disp0(Scalars *sc) { sc->max_disp2_bits = 0ull; }
+
 // before a prune step: the displacement maximum since the build is recomputed by that step
-__global__ void k_reset_d1(Scalars *sc) { sc->d1max2_bits = 0ull; }
+// (skipped, like the step itself, when an earlier step of the window recorded a violation)
+__global__ void k_reset_d1(Scalars *sc, int step)
+{
+    if (step >= 0 && sc->first_viol <= step) return;
+    sc->d1max2_bits = 0ull;
+}
 
 void alloc_state(md_ctx *c, int which, int64_t cap)
 {
@@ -592,7 +601,7 @@ void launch_force_tpu(md_ctx *c, bool want_uw, bool kick, double dt, int step, i
     double rin = c->rc + c->inner_skin;
     if (prune_step) {
         for (int d = 0; d < 3; ++d) s.x1[d] = c->x1[d].p; // the prune step writes the new reference positions
-        k_reset_d1<<<1, 1, 0, c->stream>>>(c->scal.p);
+        k_reset_d1<<<1, 1, 0, c->stream>>>(c->scal.p, step);
     }
 #define LF(UW, KK)                                                                                                  \
     k_force<D, POT, UNIFORM, UW, KK><<<nb, MD_BLOCK, 0, c->stream>>>(n, s, c->pp, c->nlist.p, c->maxn,              \
@@ -1009,7 +1018,7 @@ int md_set_skin(md_ctx *ctx, double skin)
         }
     }
     ctx->target_interval = 8;
-    ctx->prune_target = 6;
+    ctx->rate_known = false;
     API_END
 }
 
@@ -1019,7 +1028,7 @@ int md_set_inner_skin(md_ctx *ctx, double inner_skin)
     if (!(inner_skin >= 0.0)) throw HipError("md_set_inner_skin: must be >= 0");
     ctx->inner_skin_req = inner_skin;
     ctx->list_valid = false;
-    ctx->prune_target = 6;
+    ctx->rate_known = false;
     API_END
 }
 
@@ -1036,6 +1045,7 @@ int md_upload(md_ctx *ctx, const double *x, const double *v, const double *f, co
     if (v) {
         ctx->io_v.ensure(nd);
         HIPCHK(hipMemcpyAsync(ctx->io_v.p, v, nd * sizeof(double), hipMemcpyHostToDevice, st));
+        ctx->rate_known = false; // new velocities: re-measure the displacement rate the schedule is planned on
     }
     if (f) {
         ctx->io_f.ensure(nd);
@@ -1186,39 +1196,78 @@ int md_run(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, double tau, dou
             force_part(t);
         }
     } else {
-        // Chunks of steps are enqueued without host round-trips.  The drift kernel records the first
+        // Windows of steps are enqueued without host round-trips.  The drift kernel records the first
         // step at which a particle left the validity radius of the rows in use (`first_viol`); every
-        // later kernel of the chunk skips itself.  With pruning on, the rows in use are the inner
-        // rows: refreshing them is a cheap prune; the outer rows are rebuilt only when the
-        // displacement accumulated since the build (d1, measured by the prune) nears skin/2.
-        // refresh: either rebuild the outer rows, or just mark the inner rows stale so that the next
-        // force evaluation is a prune step.  Returns true if it rebuilt (ghosts are then fresh).
-        auto refresh = [&](double d1) -> bool {
-            // the next prune interval may add up to inner_skin/2 (+ a step of overshoot) to d1
-            bool need_build = !ctx->prune_on || (d1 + 0.75 * ctx->inner_skin >= 0.5 * ctx->skin);
-            if (need_build) {
-                rebuild(ctx);
-                return true;
-            }
-            ctx->inner_valid = false;
-            return false;
+        // later kernel of the window skips itself, so speculation is safe and a window can span a whole
+        // rebuild interval: one synchronisation per list build.
+        //
+        // With pruning on, the rows in use are the inner rows (cutoff + inner_skin): every L steps the force
+        // evaluation is a prune step that rewrites them from the outer rows (cutoff + skin), and the outer
+        // rows are rebuilt every R steps.  R and L follow from the measured growth rate of the largest
+        // displacement (max_i |x_i - x_ref_i| grows ballistically, ~ rate * steps):
+        //     rate * (R - 1) <= safety * skin/2          (outer rows valid at every step that uses them)
+        //     1.1 * rate * (L - 1) <= safety * inner/2   (inner rows valid between two prunes)
+        // with the segments evened out, L = ceil(R / ceil(R / Lmax)).  The device checks are the exact
+        // criteria; the plan only has to make violations rare, and `safety` backs off when they happen.
+        auto measure_disp0 = [&]() -> double {
+            k_reset_disp0<<<1, 1, 0, st>>>(ctx->scal.p);
+            DevState sd = ctx->dev(ctx->cur);
+            if (ctx->dim == 3)
+                k_max_disp0<3><<<ctx->nblk, MD_BLOCK, 0, st>>>((int)ctx->n, sd, ctx->scal.p);
+            else
+                k_max_disp0<2><<<ctx->nblk, MD_BLOCK, 0, st>>>((int)ctx->n, sd, ctx->scal.p);
+            Scalars h2 = read_scalars(ctx);
+            double d0sq;
+            unsigned long long bits = h2.max_disp2_bits;
+            memcpy(&d0sq, &bits, sizeof d0sq);
+            return std::sqrt(d0sq);
         };
         int s = 0;
+        std::vector<int> prune_steps;
         while (s < (int)nsteps) {
-            bool pruning = ctx->prune_on;
-            // if the inner rows are stale, the chunk's first force evaluation is a prune step and its drift
-            // is checked against the OUTER rows' validity
-            bool starts_with_prune = ctx->prune_on && !ctx->inner_valid;
-            if (starts_with_prune) ctx->steps_since_prune = 0;
-            int64_t target = pruning ? ctx->prune_target : ctx->target_interval;
-            int64_t since = pruning ? ctx->steps_since_prune : ctx->steps_since_build;
-            int64_t room = std::max<int64_t>(1, target - since);
-            int chunk_end = (int)std::min<int64_t>(nsteps, (int64_t)s + room);
-            for (int t = s; t < chunk_end; ++t) {
+            const bool pruning = ctx->prune_on;
+            int64_t R, L = INT64_MAX;
+            if (!pruning) {
+                R = ctx->target_interval;
+            } else if (!ctx->rate_known) {
+                R = ctx->steps_since_build + 4; // a short first window, measured at its end
+                L = 4;
+            } else {
+                double r_out = std::max(ctx->d1_rate, 1e-12);
+                double Rf = std::floor(ctx->safety * 0.5 * ctx->skin / r_out) + 1.0;
+                double Lf = std::floor(ctx->safety * 0.5 * ctx->inner_skin / (1.1 * r_out)) + 1.0;
+                int64_t Rmax = (int64_t)std::min(std::max(Rf, 2.0), 4096.0);
+                int64_t Lmax = (int64_t)std::min(std::max(Lf, 2.0), 4096.0);
+                // a build costs about as much as 8 prune steps: take the R <= Rmax with the least
+                // (build + prunes) per step -- a whole number of full segments often beats a ragged last one
+                R = Rmax;
+                double best = 1e300;
+                for (int64_t r = std::max<int64_t>(2, Rmax - Lmax); r <= Rmax; ++r) {
+                    double cost = (8.0 + (double)((r + Lmax - 1) / Lmax)) / (double)r;
+                    if (cost <= best) {
+                        best = cost;
+                        R = r;
+                    }
+                }
+                int64_t nseg = (R + Lmax - 1) / Lmax;
+                L = (R + nseg - 1) / nseg;
+            }
+            int win_cap = (int)std::min<int64_t>(nsteps, (int64_t)s + std::max<int64_t>(1, R - ctx->steps_since_build));
+            prune_steps.clear();
+            int last_prune = -1;
+            for (int t = s; t < win_cap; ++t) {
+                if (pruning && ctx->inner_valid && ctx->steps_since_prune >= L)
+                    ctx->inner_valid = false; // scheduled refresh of the inner rows
+                if (pruning && !ctx->inner_valid) {
+                    prune_steps.push_back(t);
+                    last_prune = t;
+                }
                 launch_kickdrift(ctx, nvt, dt, true, t);
                 launch_ghost_update(ctx, t);
-                force_part(t);
+                force_part(t); // (a prune step marks the inner rows valid and zeroes steps_since_prune)
+                ctx->steps_since_prune += 1;
             }
+            int win_end = win_cap;
             HIPCHK(hipGetLastError());
             Scalars h = read_scalars(ctx);
             double d1 = 0.0;
@@ -1228,27 +1277,46 @@ int md_run(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, double tau, dou
                 memcpy(&d12, &bits, sizeof d12);
                 d1 = std::sqrt(d12);
             }
-            if (h.first_viol < chunk_end) {
+            if (getenv("MDHIP_TRACE_WINDOWS"))
+                fprintf(stderr, "[mdhip] window %d..%d viol %d d1 %.4f rate %.5f safety %.3f since_build %lld R %lld L %lld nprune %zu\n",
+                        s, win_end, h.first_viol < win_end ? h.first_viol : -1, d1, ctx->d1_rate, ctx->safety,
+                        (long long)ctx->steps_since_build, (long long)R, (long long)(L == INT64_MAX ? -1 : L),
+                        prune_steps.size());
+            if (h.first_viol < win_end) {
                 // everything from step m's force evaluation on was skipped on the device: refresh the
                 // rows at the drifted positions and resume with the force half of step m
                 int m = h.first_viol;
                 if (m < s) throw HipError("internal: stale displacement-violation index");
                 ctx->st_viol++;
-                int64_t observed = since + (m - s) + 1;
-                int64_t nt = std::max<int64_t>(2, (observed * 4) / 5);
-                if (pruning)
-                    ctx->prune_target = nt;
-                else
-                    ctx->target_interval = nt;
+                bool m_was_prune = false;
+                for (int p : prune_steps)
+                    if (p == m) m_was_prune = true;
                 ctx->steps_since_build += (m - s) + 1;
                 bool rebuilt;
-                if (starts_with_prune && m == s) {
-                    // the violated criterion was the outer rows' (the prune step itself was skipped, its d1
-                    // is meaningless): only a rebuild helps
+                if (!pruning) {
+                    int64_t observed = ctx->steps_since_build;
+                    ctx->target_interval = std::max<int64_t>(2, (observed * 4) / 5);
                     rebuild(ctx);
                     rebuilt = true;
                 } else {
-                    rebuilt = refresh(d1);
+                    ctx->safety = std::max(0.5, ctx->safety - 0.02);
+                    // the largest displacement since the build is both a fresh sample of the rate and the exact
+                    // test of whether the outer rows can still serve a prune step at the drifted positions
+                    double d0 = measure_disp0();
+                    double sample = d0 / (double)ctx->steps_since_build;
+                    if (!ctx->rate_known)
+                        ctx->d1_rate = sample;
+                    else if (sample > ctx->d1_rate)
+                        ctx->d1_rate = 0.5 * (ctx->d1_rate + sample);
+                    ctx->rate_known = true;
+                    // (a prune this late would buy only a few steps: rebuild unless a full segment still fits)
+                    if (m_was_prune || !(d0 + 0.5 * ctx->inner_skin <= 0.5 * ctx->skin)) {
+                        rebuild(ctx);
+                        rebuilt = true;
+                    } else {
+                        ctx->inner_valid = false;
+                        rebuilt = false;
+                    }
                 }
                 if (!rebuilt) {
                     // a prune step follows: consume the recorded violation, and redo the ghost refresh that
@@ -1257,20 +1325,28 @@ int md_run(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, double tau, dou
                     launch_ghost_update(ctx, -1);
                 }
                 force_part(m);
+                ctx->steps_since_prune = 1;
                 s = m + 1;
             } else {
-                ctx->steps_since_build += chunk_end - s;
-                ctx->steps_since_prune += chunk_end - s;
-                s = chunk_end;
-                since += room;
-                if (s < (int)nsteps && since >= target) {
-                    // scheduled refresh just ahead of the expected violation; creep the interval up so
-                    // that it tracks the true one from below
-                    refresh(d1);
-                    if (pruning)
-                        ctx->prune_target += 1;
-                    else
-                        ctx->target_interval += 1;
+                ctx->steps_since_build += win_end - s;
+                s = win_end;
+                if (pruning) {
+                    if (!ctx->rate_known) {
+                        ctx->d1_rate = measure_disp0() / (double)ctx->steps_since_build;
+                        ctx->rate_known = true;
+                    } else {
+                        // d1 belongs to the window's last prune step
+                        int64_t b_last = ctx->steps_since_build - (win_end - 1 - last_prune) - 1;
+                        if (last_prune >= 0 && b_last > 0)
+                            ctx->d1_rate = 0.7 * ctx->d1_rate + 0.3 * (d1 / (double)b_last);
+                        ctx->safety = std::min(0.99, ctx->safety + 0.002);
+                        if (s < (int)nsteps && ctx->steps_since_build >= R) rebuild(ctx);
+                    }
+                } else if (s < (int)nsteps && ctx->steps_since_build >= ctx->target_interval) {
+                    // scheduled rebuild just ahead of the expected violation; creep the interval up so that it
+                    // tracks the true one from below
+                    rebuild(ctx);
+                    ctx->target_interval += 1;
                 }
             }
         }
