@@ -224,7 +224,7 @@ def main():
             "particles_per_gpu": a.n,
             "parallelism": "1 GPU" if world == 1 else f"{world}-way 1-D slab decomposition along x, halo exchange every "
                                                             f"step over torch.distributed ({dist.get_backend()})",
-            "skin": a.skin if a.skin is not None else 0.4,
+            "skin": a.skin if a.skin is not None else (0.6 if world == 1 else 0.4),
             "rebuilds_in_timed_region": st1["rebuilds"] - st0["rebuilds"],
             "global_particles": total_particles,
             "avg_list_candidates": st1["avg_neighbors"],

@@ -63,12 +63,13 @@ int md_set_potential_source(md_ctx *ctx, const char *hip_src, const char *entry_
 /* Verlet-list skin.  skin = 0 rebuilds the linked cells every step exactly as
  * CellListMap.map_pairwise! does (src/simulation.jl:100-104); skin > 0 reuses a neighbour
  * list built with cutoff+skin until some particle has moved skin/2 -- the accepted pair set
- * of every step is unchanged (pairs are still filtered by d^2 <= list_cutoff^2).          */
+ * of every step is unchanged (pairs are still filtered by d^2 <= list_cutoff^2).  Default: 0.6
+ * (0.4 for a slab-decomposition handle), clipped to what the box allows.                  */
 int md_set_skin(md_ctx *ctx, double skin);
 
 /* Dynamic pruning of the rows: every few steps the rows the force kernel walks are refreshed from
  * the Verlet rows, keeping the entries within list_cutoff + inner_skin at that moment.  Results are
- * unchanged (only sure misses are dropped, order kept); inner_skin = 0 turns it off.  Default 0.10. */
+ * unchanged (only sure misses are dropped, order kept); inner_skin = 0 turns it off.  Default 0.16. */
 int md_set_inner_skin(md_ctx *ctx, double inner_skin);
 
 /* State transfer; any pointer may be NULL (= leave that array as it is on the device).

@@ -771,15 +771,8 @@ __global__ void __launch_bounds__(MD_TILE)
     const double4 *__restrict__ P = s.pos;
     int H = halo_count[bid];
     const uint32_t *hl = halo + (size_t)bid * hcap;
-    for (int h = threadIdx.x; h <= H; h += MD_TILE) {
-        double4 p = (h < H) ? P[hl[h]] : make_double4(MD_SENTINEL_POS, MD_SENTINEL_POS, MD_SENTINEL_POS, 1.0);
-        double *rec = (double *)(smem + (size_t)h * RS);
-        rec[0] = p.x;
-        rec[1] = p.y;
-        rec[2] = (D == 3) ? p.z : 0.0;
-        if constexpr (!UNIFORM) rec[3] = p.w;
-    }
-    __syncthreads();
+    // this thread's own loads (row length, first index groups, position, velocity) go out ahead of the
+    // staging so that their latency is covered by it
     int k = bid * MD_TILE + threadIdx.x;
     bool active = k < n;
     int kk = active ? k : n - 1;
@@ -791,16 +784,48 @@ __global__ void __launch_bounds__(MD_TILE)
     int cin = 0;
     int m = nmax_tile[wt];
     double4 pi = P[kk];
+    constexpr int G = MD_UNROLL / 4; // index groups per iteration
+    ushort4 jn[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) jn[g] = row4[(size_t)((4 * g < m) ? g : 0) * 64];
+    double v0[3] = {0.0, 0.0, 0.0};
+    if constexpr (KICK) {
+#pragma unroll
+        for (int c = 0; c < D; ++c) v0[c] = s.v[c][kk];
+    }
+    // stage the halo: all of a thread's index loads are issued first, then all its gathers, so that the
+    // dependent index -> record chain is paid once per 8 records instead of once per record
+    for (int h0 = 0; h0 <= H; h0 += 8 * MD_TILE) {
+        uint32_t idx[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int h = h0 + i * MD_TILE + threadIdx.x;
+            idx[i] = (h < H) ? hl[h] : 0xffffffffu;
+        }
+        double4 pr[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            pr[i] = (idx[i] != 0xffffffffu) ? P[idx[i]]
+                                            : make_double4(MD_SENTINEL_POS, MD_SENTINEL_POS, MD_SENTINEL_POS, 1.0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int h = h0 + i * MD_TILE + threadIdx.x;
+            if (h <= H) {
+                double *rec = (double *)(smem + (size_t)h * RS);
+                rec[0] = pr[i].x;
+                rec[1] = pr[i].y;
+                rec[2] = (D == 3) ? pr[i].z : 0.0;
+                if constexpr (!UNIFORM) rec[3] = pr[i].w;
+            }
+        }
+    }
+    __syncthreads();
     double fx = 0.0, fy = 0.0, fz = 0.0, us = 0.0, ws = 0.0;
     // Two index groups (8 candidates) per iteration: all their LDS reads are issued before the first
     // use, which is what hides the LDS latency at 4 waves per SIMD.  The indices of the next pair of
     // groups are fetched while this one is computed.  A row has a multiple of 4 entries; when the
     // second group of the last pair does not exist its offsets are replaced by the sentinel record.
     const unsigned sent_off = (unsigned)H * RS;
-    constexpr int G = MD_UNROLL / 4; // index groups per iteration
-    ushort4 jn[G];
-#pragma unroll
-    for (int g = 0; g < G; ++g) jn[g] = row4[(size_t)((4 * g < m) ? g : 0) * 64];
     for (int r = 0; r < m; r += MD_UNROLL) {
         unsigned o[MD_UNROLL];
 #pragma unroll
@@ -893,13 +918,13 @@ __global__ void __launch_bounds__(MD_TILE)
         s.f[1][k] = fy;
         if constexpr (D == 3) s.f[2][k] = fz;
         if constexpr (KICK) {
-            double vx = s.v[0][k] + (fx * dt) / 2.0;
-            double vy = s.v[1][k] + (fy * dt) / 2.0;
+            double vx = v0[0] + (fx * dt) / 2.0;
+            double vy = v0[1] + (fy * dt) / 2.0;
             s.v[0][k] = vx;
             s.v[1][k] = vy;
             ke = vx * vx + vy * vy;
             if constexpr (D == 3) {
-                double vz = s.v[2][k] + (fz * dt) / 2.0;
+                double vz = v0[2] + (fz * dt) / 2.0;
                 s.v[2][k] = vz;
                 ke += vz * vz;
             }

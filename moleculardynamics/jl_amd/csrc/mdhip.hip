@@ -101,7 +101,8 @@ struct md_ctx {
     } dom;
     double L[3] = {1, 1, 1};
     double rc = 0.0;       // list cutoff (CellListMap's cutoff)
-    double skin_req = 0.4; // requested skin (0.4 measured best for LJ r_c=2.5 at N=2^20: see DESIGN.md)
+    double skin_req = 0.6; // requested skin.  Measured best for LJ r_c=2.5 at N=2^20: 0.6 with inner rows
+                           // (inner skin 0.16), 0.4 without them
     double skin = 0.0;     // effective skin
     double rl = 0.0;       // rc + skin
     int pot_kind = POT_LJ;
@@ -150,7 +151,7 @@ struct md_ctx {
     int64_t steps_since_build = 0;
     int64_t target_interval = 8;
     // dynamic pruning of the rows (single-GPU handles with a skin): inner rows used by the force kernel
-    double inner_skin_req = 0.10; // prune step every ~7 steps at dt=0.001, kT~1.5 (measured +2 % at N=2^20)
+    double inner_skin_req = 0.16; // prune step every ~10 steps at dt=0.001, kT~1.5
     double inner_skin = 0.0;
     bool inner_valid = false; // the inner rows exist and the force kernel uses them
     bool prune_on = false;    // this build supports inner rows (tiled path, skin > inner skin > 0, single GPU)
@@ -850,6 +851,7 @@ static int create_common(int dim, int64_t n_global, int64_t n_cap, bool domain, 
         ctx->rc = list_cutoff;
         if (domain) {
             ctx->dom.on = true;
+            ctx->skin_req = 0.4; // no inner rows on the slab path yet: the single-list optimum
             ctx->dom.rank = rank;
             ctx->dom.nranks = nranks;
             ctx->dom.xlo = ctx->L[0] * rank / nranks;
