@@ -40,6 +40,7 @@ struct DevState {
     int32_t *id;   // cap+1: original particle index (ghost: its owner's)
     double *x0[3]; // n: positions at the last list build
     double *x1[3]; // n: positions at the last prune of the rows (== x0 when pruning is off)
+    double boxL[3]; // global box lengths (periodic translation of virtual ghosts in the tiled force kernel)
 };
 
 struct BoxGrid {
@@ -484,6 +485,20 @@ __global__ void __launch_bounds__(MD_BLOCK)
 }
 
 // ghost copies follow their owners between builds: x_ghost = x_owner + s*L
+// Rewrites the ghost entries of every tile's halo list as (owner slot | shift code << 26): "virtual ghosts"
+// for the tiled force kernel (which then never reads a ghost record).  One block per tile.
+__global__ void __launch_bounds__(MD_BLOCK)
+    k_halo_virtualize(int n, uint32_t *__restrict__ halo, int hcap, const int32_t *__restrict__ halo_count,
+                      const int32_t *__restrict__ gowner, const uint32_t *__restrict__ gcode)
+{
+    uint32_t *hl = halo + (size_t)blockIdx.x * hcap;
+    int H = halo_count[blockIdx.x];
+    for (int h = threadIdx.x; h < H; h += blockDim.x) {
+        uint32_t e = hl[h];
+        if (e >= (uint32_t)n) hl[h] = (uint32_t)gowner[e - n] | (gcode[e - n] << 26);
+    }
+}
+
 template <int D>
 __global__ void __launch_bounds__(MD_BLOCK)
     k_ghost_update(int n, int nghost, DevState s, BoxGrid g, const int32_t *__restrict__ gowner,
@@ -802,11 +817,28 @@ __global__ void __launch_bounds__(MD_TILE)
             int h = h0 + i * MD_TILE + threadIdx.x;
             idx[i] = (h < H) ? hl[h] : 0xffffffffu;
         }
+        // A halo entry is a slot (26 bits) plus a periodic shift code (6 bits, see shifted()): with virtual
+        // ghosts the slot is the ghost's OWNER and the ghost's coordinates x_owner + s*L are formed here, the
+        // same single addition k_ghost_update would have done -- so nothing has to refresh ghost records
+        // between the drift and this kernel.
         double4 pr[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-            pr[i] = (idx[i] != 0xffffffffu) ? P[idx[i]]
+            pr[i] = (idx[i] != 0xffffffffu) ? P[idx[i] & 0x3ffffffu]
                                             : make_double4(MD_SENTINEL_POS, MD_SENTINEL_POS, MD_SENTINEL_POS, 1.0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            uint32_t code = (idx[i] != 0xffffffffu) ? (idx[i] >> 26) : 0u;
+            if (code) {
+                uint32_t sx = code & 3u, sy = (code >> 2) & 3u, sz = (code >> 4) & 3u;
+                if (sx == 1u) pr[i].x = pr[i].x + s.boxL[0];
+                if (sx == 2u) pr[i].x = pr[i].x - s.boxL[0];
+                if (sy == 1u) pr[i].y = pr[i].y + s.boxL[1];
+                if (sy == 2u) pr[i].y = pr[i].y - s.boxL[1];
+                if (sz == 1u) pr[i].z = pr[i].z + s.boxL[2];
+                if (sz == 2u) pr[i].z = pr[i].z - s.boxL[2];
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             int h = h0 + i * MD_TILE + threadIdx.x;
@@ -1103,9 +1135,21 @@ __global__ void __launch_bounds__(MD_BLOCK)
     for (int r = 0; r < cnt; ++r) {
         // rows are either 32-bit global slots or 16-bit indices into the tile's halo list
         uint32_t j = nlist16 ? hl[nlist16[tbase + row_off(r, lane)] / (unsigned)rs] : nlist[tbase + lane + (size_t)r * 64];
+        // (a halo entry may be a virtual ghost: owner slot | shift code << 26)
+        uint32_t code = nlist16 ? (j >> 26) : 0u;
+        if (nlist16) j &= 0x3ffffffu;
         int b = s.id[j];
         if (a >= b) continue;
         double4 pj = s.pos[j];
+        if (code) {
+            uint32_t sx = code & 3u, sy = (code >> 2) & 3u, sz = (code >> 4) & 3u;
+            if (sx == 1u) pj.x = pj.x + s.boxL[0];
+            if (sx == 2u) pj.x = pj.x - s.boxL[0];
+            if (sy == 1u) pj.y = pj.y + s.boxL[1];
+            if (sy == 2u) pj.y = pj.y - s.boxL[1];
+            if (sz == 1u) pj.z = pj.z + s.boxL[2];
+            if (sz == 2u) pj.z = pj.z - s.boxL[2];
+        }
         double dx = pj.x - pk.x;
         double dy = pj.y - pk.y;
         double d2 = dx * dx;

@@ -153,6 +153,7 @@ struct md_ctx {
     // dynamic pruning of the rows (single-GPU handles with a skin): inner rows used by the force kernel
     double inner_skin_req = 0.16; // prune step every ~10 steps at dt=0.001, kT~1.5
     double inner_skin = 0.0;
+    bool virtual_ghosts = false; // halo entries of ghosts are (owner | shift code << 26): no per-step ghost refresh
     bool inner_valid = false; // the inner rows exist and the force kernel uses them
     bool prune_on = false;    // this build supports inner rows (tiled path, skin > inner skin > 0, single GPU)
     DBuf<double> x1[3];
@@ -187,6 +188,7 @@ struct md_ctx {
             s.x1[c] = (inner_valid && x1[c].p) ? x1[c].p : b.x0[c].p;
         }
         s.id = b.id.p;
+        for (int c = 0; c < 3; ++c) s.boxL[c] = c < dim ? L[c] : 0.0;
         return s;
     }
 };
@@ -532,6 +534,11 @@ void rebuild_t(md_ctx *c)
             set_tiles(h);
         }
     }
+    // single-GPU tiled path: ghosts become (owner, shift) references resolved while staging the halo, and the
+    // per-step ghost refresh disappears.  (Slab decomposition keeps real ghost records: they arrive by message.)
+    c->virtual_ghosts = c->use_tiles && !c->dom.on && c->cap < (1ll << 26);
+    if (c->virtual_ghosts && nghost > 0)
+        k_halo_virtualize<<<c->nblk, MD_BLOCK, 0, st>>>(n, c->halo.p, c->hcap, c->halo_count.p, c->gowner.p, c->gcode.p);
     c->list_valid = true;
     c->steps_since_build = 0;
     c->st_rebuilds++;
@@ -758,7 +765,7 @@ void launch_kickdrift(md_ctx *c, bool nvt, double dt, bool check, int step)
 
 void launch_ghost_update(md_ctx *c, int step)
 {
-    if (c->nghost == 0) return;
+    if (c->nghost == 0 || c->virtual_ghosts) return;
     DevState s = c->dev(c->cur);
     int nb = nblocks(c->nghost);
     if (c->dim == 3)
