@@ -110,9 +110,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
-    if world > 1:
+    # MDHIP_BENCH_DOMAIN=1: run the slab-decomposition code path with a single rank (its two x-neighbours are
+    # itself; RCCL carries the self-exchange) -- measures the multi-GPU path's per-GPU cost on a one-GPU box
+    use_domain = world > 1 or os.environ.get("MDHIP_BENCH_DOMAIN", "0") == "1"
+    if use_domain:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         backend = os.environ.get("MDHIP_BENCH_BACKEND", "nccl")   # "gloo": functional runs of several ranks on one GPU
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
@@ -130,7 +136,7 @@ def main():
     dt, tau = 0.001, 0.1
     nvt = a.ensemble == "nvt"
     inp = make_inputs(a.n, seed_shift=rank)
-    if world == 1:
+    if not use_domain:
         nf = 3.0 * (a.n - 1.0)
         dev = MDDevice(3, a.n, inp["box"], 2.5, device_id=local_rank)
         dev.set_potential(_lib.MD_POT_LJ, [1.0, 1.0, 2.5])
@@ -167,14 +173,23 @@ def main():
         dev.upload_local(ids, xg, inp["v"], inp["f"], inp["img"], inp["diam"])
         rng = np.random.default_rng(4242)      # the same stream on every rank: identical thermostat noise
 
+        # step loop (MDHIP_DOM_LOOP): "native" = windows of steps inside the library, RCCL issued by the library
+        # (default with one GPU per rank); "async" = the same scheme driven from Python through
+        # torch.distributed, stream-ordered; "sync" = one host round trip per phase (host-staged gloo runs)
+        loop = os.environ.get("MDHIP_DOM_LOOP", "native" if ex.p2p_on_device else ("async" if ex.on_device else "sync"))
+        if os.environ.get("MDHIP_DOM_SYNC", "0") == "1":
+            loop = "sync"
+        stepper = {"sync": dev.run, "async": dev.run_async, "native": dev.run_native}[loop]
+        sync_loop = loop == "sync"
+
         def run(nsteps, thermo=False):
             if nsteps <= 0:
                 return None
             if nvt:
                 kt = np.full(nsteps, inp["kT"])
                 r1, r2 = draw_bussi(nf, rng, nsteps)
-                return dev.run(nsteps, dt, _lib.MD_NVT, tau, nf, kt, r1, r2)
-            return dev.run(nsteps, dt, _lib.MD_NVE)
+                return stepper(nsteps, dt, _lib.MD_NVT, tau, nf, kt, r1, r2)
+            return stepper(nsteps, dt, _lib.MD_NVE)
 
     def barrier():
         if dist is not None:
@@ -222,9 +237,10 @@ def main():
             "workload": f"BASELINE configs[2]: N={a.n} monodisperse LJ 3D rho=0.897 r_cut=2.5 dt=0.001 "
                         f"{'NVT Bussi tau=0.1 kT=1.4737' if nvt else 'NVE'}, per GPU",
             "particles_per_gpu": a.n,
-            "parallelism": "1 GPU" if world == 1 else f"{world}-way 1-D slab decomposition along x, halo exchange every "
-                                                            f"step over torch.distributed ({dist.get_backend()})",
-            "skin": a.skin if a.skin is not None else (0.6 if world == 1 else 0.4),
+            "parallelism": "1 GPU" if not use_domain else f"{world}-way 1-D slab decomposition along x, halo exchange every "
+                                                            f"step over torch.distributed ({dist.get_backend()}), "
+                                                            f"step loop: {loop}",
+            "skin": a.skin if a.skin is not None else (0.4 if use_domain else 0.6),
             "rebuilds_in_timed_region": st1["rebuilds"] - st0["rebuilds"],
             "global_particles": total_particles,
             "avg_list_candidates": st1["avg_neighbors"],
@@ -239,7 +255,7 @@ def main():
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": measured_traffic() if (world == 1 and a.n == 1048576) else None,
+            "traffic": measured_traffic() if (not use_domain and a.n == 1048576) else None,
             "kernel_ms": kern_ms,
             "kernel_launches": launches,
             "bytes_per_launch": FORCE_KERNEL_BYTES * a.n,

@@ -171,6 +171,38 @@ int md_dom_forces(md_ctx *ctx, double dt, int kick, int want_uw, double *uwk);
 int md_dom_set_scale(md_ctx *ctx, double scale);
 int md_dom_counts(md_ctx *ctx, int64_t *out /* [6]: n_own, nsend_halo L,R, nrecv_halo L,R, n_ghost */);
 
+/* Asynchronous slab stepping -- none of these waits for the device.  The caller enqueues on ONE stream, per
+ * step,   md_dom_step_a -> all-reduce(MIN) of *flag_dev + neighbour exchange of the step buffers ->
+ *         md_dom_step_b -> all-reduce(SUM) of kuw_dev[3] -> md_dom_step_c
+ * (the last two only for MD_NVT or on a step that reports U/W/K), a whole window of steps at a time, with
+ * 0-based step numbers inside the window; ktemp/r1/r2 are indexed by them (same meaning as md_run's).  A
+ * displacement violation on any rank at step m reaches every rank through the reduced flag before step m's
+ * force evaluation: all later kernels of the window skip themselves on every rank (the single-GPU scheme of
+ * md_run, made global).  md_dom_async_end waits, reports m (0x7fffffff = none) and the global {U, W, K};
+ * after a violation the caller rebuilds (migrate/halo/build) and calls md_dom_forces for step m.
+ * md_set_stream makes the handle launch on the caller's hipStream_t (NULL = its own again), so that
+ * stream-ordered RCCL calls interleave with the kernels without host synchronisation.                    */
+int md_set_stream(md_ctx *ctx, void *hip_stream);
+int md_dom_async_begin(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, double tau, double nf, const double *ktemp,
+                       const double *r1, const double *r2, void *flag_dev /* int32[1] */, void *kuw_dev /* double[3] */);
+int md_dom_step_a(md_ctx *ctx, double dt, int step);
+int md_dom_step_b(md_ctx *ctx, double dt, int step, int want_uw);
+int md_dom_step_c(md_ctx *ctx, int step, int want_uw);
+int md_dom_async_end(md_ctx *ctx, int apply_pending_scale, int32_t *first_viol, double *uwk);
+
+/* Native transport: the same window of steps run entirely inside the library, which issues the three small
+ * collectives of a step itself -- RCCL (over xGMI) on the handle's stream.  RCCL is bound at run time from
+ * rccl_path (NULL = "librccl.so"; a PyTorch host passes the copy torch has loaded so that one RCCL lives in
+ * the process).  Rank 0 obtains the 128-byte unique id and distributes it by any means; every rank then calls
+ * md_dom_comm_init (collective; it ends with an all-reduce self-test).  md_dom_run_window = md_dom_async_begin
+ * + nsteps x (step_a, all-reduce MIN, neighbour send/recv, step_b, all-reduce SUM, step_c) + md_dom_async_end;
+ * report_last asks for the global U, W of the window's last step.  List builds stay with the caller.        */
+int md_dom_comm_unique_id(const char *rccl_path, void *id128);
+int md_dom_comm_init(md_ctx *ctx, const char *rccl_path, const void *id128);
+int md_dom_run_window(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, double tau, double nf, const double *ktemp,
+                      const double *r1, const double *r2, int report_last, int apply_pending_scale,
+                      int32_t *first_viol, double *uwk);
+
 /* Library build info: returns e.g. "mdhip 0.1 gfx950". */
 const char *md_version(void);
 

@@ -21,7 +21,8 @@ EXPORTS = [
     "md_create_domain", "md_dom_set_uniform", "md_dom_upload", "md_dom_download", "md_dom_migrate_pack",
     "md_dom_migrate_unpack", "md_dom_halo_pack", "md_dom_halo_unpack", "md_dom_build", "md_dom_get_sendbuf",
     "md_dom_put_recvbuf", "md_dom_set_step_buffers", "md_dom_step_begin", "md_dom_step_end", "md_dom_forces", "md_dom_set_scale",
-    "md_dom_counts",
+    "md_dom_counts", "md_set_stream", "md_dom_async_begin", "md_dom_step_a", "md_dom_step_b", "md_dom_step_c",
+    "md_dom_async_end", "md_dom_comm_unique_id", "md_dom_comm_init", "md_dom_run_window",
 ]
 
 
@@ -102,8 +103,19 @@ def load():
     L.md_dom_forces.argtypes = [vp, C.c_double, C.c_int, C.c_int, dp]
     L.md_dom_set_scale.argtypes = [vp, C.c_double]
     L.md_dom_counts.argtypes = [vp, i64p]
+    L.md_set_stream.argtypes = [vp, C.c_void_p]
+    L.md_dom_async_begin.argtypes = [vp, C.c_int64, C.c_double, C.c_int, C.c_double, C.c_double, dp, dp, dp, C.c_void_p,
+                                     C.c_void_p]
+    L.md_dom_step_a.argtypes = [vp, C.c_double, C.c_int]
+    L.md_dom_step_b.argtypes = [vp, C.c_double, C.c_int, C.c_int]
+    L.md_dom_step_c.argtypes = [vp, C.c_int, C.c_int]
+    L.md_dom_async_end.argtypes = [vp, C.c_int, C.POINTER(C.c_int32), dp]
+    L.md_dom_comm_unique_id.argtypes = [C.c_char_p, C.c_void_p]
+    L.md_dom_comm_init.argtypes = [vp, C.c_char_p, C.c_void_p]
+    L.md_dom_run_window.argtypes = [vp, C.c_int64, C.c_double, C.c_int, C.c_double, C.c_double, dp, dp, dp, C.c_int, C.c_int,
+                                    C.POINTER(C.c_int32), dp]
     for name in EXPORTS:
-        if name.startswith("md_dom_") or name == "md_create_domain":
+        if name.startswith("md_dom_") or name in ("md_create_domain", "md_set_stream"):
             getattr(L, name).restype = C.c_int
     _lib = L
     return L

@@ -237,3 +237,62 @@ __global__ void __launch_bounds__(MD_BLOCK)
 }
 
 __global__ void k_reset_viol(Scalars *sc) { sc->first_viol = MD_NO_VIOLATION; }
+
+// ------------------------------------------------------------------------------------------
+// asynchronous stepping: the words the caller all-reduces between the phases of a step
+// ------------------------------------------------------------------------------------------
+__global__ void k_dom_flag_export(const Scalars *sc, int32_t *flag) { flag[0] = sc->first_viol; }
+__global__ void k_dom_flag_import(Scalars *sc, const int32_t *flag)
+{
+    if (flag[0] < sc->first_viol) sc->first_viol = flag[0];
+}
+
+// this rank's fixed-order sums of the force kernel's per-block partials: out = {sum v^2, sum u, sum w}
+__global__ void __launch_bounds__(1024)
+    k_dom_local_sums(int nblk, const double *__restrict__ partials, int want_uw, double *__restrict__ out,
+                     const Scalars *sc, int step)
+{
+    __shared__ double red[16];
+    if (sc->first_viol <= step) return;
+    double a = 0.0, b = 0.0, c = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += blockDim.x) {
+        a += partials[i];
+        if (want_uw) {
+            b += partials[nblk + i];
+            c += partials[2 * nblk + i];
+        }
+    }
+    a = block_sum(a, red);
+    b = block_sum(b, red);
+    c = block_sum(c, red);
+    if (threadIdx.x == 0) {
+        out[0] = a;
+        out[1] = b;
+        out[2] = c;
+    }
+}
+
+// the same arithmetic as k_finalize's tail, on the all-reduced sums (identical on every rank)
+__global__ void k_dom_global_finalize(const double *__restrict__ sums, int want_uw, int nvt, double nf, double term1,
+                                      const double *__restrict__ kt, const double *__restrict__ r1,
+                                      const double *__restrict__ r2, Scalars *sc, int step)
+{
+    if (sc->first_viol <= step) return;
+    double K = sums[0] / 2.0;
+    if (want_uw) {
+        sc->U = sums[1] / 2.0;
+        sc->W = sums[2] / 2.0;
+    }
+    if (nvt) {
+        double tc = 2.0 * K / nf;
+        double rr1 = r1[step], rr2 = r2[step];
+        double c2 = (1.0 - term1) * kt[step] / (tc * nf);
+        double term_2 = c2 * (rr2 + rr1 * rr1);
+        double term_3 = 2.0 * rr1 * sqrt(term1 * c2);
+        double scale = sqrt(term1 + term_2 + term_3);
+        sc->scale = scale;
+        K = K * scale * scale;
+    }
+    sc->K = K;
+    sc->T = 2.0 * K / nf;
+}

@@ -1050,6 +1050,7 @@ __global__ void __launch_bounds__(MD_BLOCK) k_scale_v(int n, DevState s, const S
 {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
+    if (use_dev == 2 && sc->first_viol != MD_NO_VIOLATION) return; // pending scale already consumed (see md_dom_async_end)
     double scale = use_dev ? sc->scale : host_scale;
 #pragma unroll
     for (int c = 0; c < D; ++c) s.v[c][k] = s.v[c][k] * scale;
@@ -1113,6 +1114,10 @@ __global__ void __launch_bounds__(1024)
 }
 
 __global__ void k_set_scale(Scalars *sc, double v) { sc->scale = v; }
+__global__ void k_set_scale_unless_violated(Scalars *sc, double v)
+{
+    if (sc->first_viol == MD_NO_VIOLATION) sc->scale = v;
+}
 
 // ------------------------------------------------------------------------------------------
 // Accepted pair set for the parity check: (min id, max id) for every list entry with

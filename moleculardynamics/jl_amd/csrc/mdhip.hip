@@ -22,6 +22,9 @@
 
 #include "../../../include/mdhip.h"
 #include "md_rtc.hpp"
+#include "md_rccl.hpp"
+
+static RcclApi g_rccl;
 
 namespace {
 
@@ -98,6 +101,16 @@ struct md_ctx {
         DBuf<double> sbuf[2], rbuf[2];
         double *ext_send[2] = {nullptr, nullptr}, *ext_recv[2] = {nullptr, nullptr}; // caller-owned step buffers
         int64_t ext_cap = 0;
+        // asynchronous stepping (md_dom_async_*): caller-owned device words the caller all-reduces between the
+        // phases of a step
+        int32_t *flag_dev = nullptr; // [1] first violating step (MIN-reduced)
+        double *kuw_dev = nullptr;   // [3] K, U, W partial sums of this rank (SUM-reduced)
+        bool a_nvt = false;
+        double a_nf = 0.0, a_term1 = 0.0;
+        // native transport (md_dom_comm_init): RCCL called by the library on the handle's stream
+        ncclComm_t comm = nullptr;
+        DBuf<int32_t> own_flag;
+        DBuf<double> own_kuw;
     } dom;
     double L[3] = {1, 1, 1};
     double rc = 0.0;       // list cutoff (CellListMap's cutoff)
@@ -111,7 +124,8 @@ struct md_ctx {
     bool uniform_sigma = true;
     double sigma_u = 1.0;
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;     // the stream every kernel of the handle runs on
+    hipStream_t own_stream = nullptr; // the one created with the handle (stream may be the caller's: md_set_stream)
 
     int64_t cap = 0;  // extended capacity: owned + ghosts (sentinel lives at index cap)
     int64_t next = 0; // owned + ghosts of the last build
@@ -830,8 +844,8 @@ static int create_common(int dim, int64_t n_global, int64_t n_cap, bool domain, 
     if (n_global >= (1ll << 31)) return fail(nullptr, "md_create: particle ids must fit 31 bits");
     if (!box) return fail(nullptr, "md_create: box is null");
     if (!(list_cutoff > 0.0)) return fail(nullptr, "md_create: list_cutoff must be positive");
-    if (domain && (nranks < 2 || rank < 0 || rank >= nranks))
-        return fail(nullptr, "md_create_domain: need nranks >= 2 and 0 <= rank < nranks");
+    if (domain && (nranks < 1 || rank < 0 || rank >= nranks))
+        return fail(nullptr, "md_create_domain: need nranks >= 1 and 0 <= rank < nranks");
     for (int r = 0; r < dim; ++r)
         for (int c = 0; c < dim; ++c) {
             double v = box[c * dim + r];
@@ -850,6 +864,7 @@ static int create_common(int dim, int64_t n_global, int64_t n_cap, bool domain, 
         ctx->device = device_id;
         HIPCHK(hipSetDevice(device_id));
         HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        ctx->own_stream = ctx->stream;
         ctx->dim = dim;
         ctx->n_global = n_global;
         ctx->ncap = n_cap;
@@ -961,10 +976,12 @@ int md_destroy(md_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) {
         (void)hipStreamSynchronize(ctx->stream);
-        (void)hipStreamDestroy(ctx->stream);
+        (void)hipStreamDestroy(ctx->own_stream);
     }
     delete ctx->rtc;
     ctx->rtc = nullptr;
+    if (ctx->dom.comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(ctx->dom.comm);
+    ctx->dom.comm = nullptr;
     for (auto &p : ctx->prof_ev) {
         (void)hipEventDestroy(p.first);
         (void)hipEventDestroy(p.second);
@@ -1828,6 +1845,239 @@ int md_dom_forces(md_ctx *ctx, double dt, int kick, int want_uw, double *uwk)
         uwk[1] = (ctx->n > 0 && want_uw) ? h.W : 0.0;
         uwk[2] = (ctx->n > 0 && kick) ? h.K : 0.0;
     }
+    API_END
+}
+
+// ---------------------------------------------------------------------------------------------
+// Asynchronous slab stepping: none of these waits for the device.  The caller enqueues, per step,
+//   md_dom_step_a -> all-reduce(MIN) of flag_dev  +  neighbour exchange of the step buffers
+//   md_dom_step_b -> all-reduce(SUM) of kuw_dev   (NVT, or when the step reports U/W/K)
+//   md_dom_step_c
+// on the handle's stream (md_set_stream: the caller's stream, so that its RCCL calls are ordered with the
+// kernels), a whole window of steps at a time.  A displacement violation on any rank at step m reaches
+// every rank through the reduced flag before step m's force evaluation: all later kernels of the window
+// skip themselves on every rank, exactly as on one GPU.  md_dom_async_end waits and reports m.
+// ---------------------------------------------------------------------------------------------
+int md_set_stream(md_ctx *ctx, void *stream)
+{
+    API_BEGIN
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    ctx->stream = stream ? (hipStream_t)stream : ctx->own_stream;
+    API_END
+}
+
+int md_dom_async_begin(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, double tau, double nf,
+                       const double *ktemp, const double *r1, const double *r2, void *flag_dev, void *kuw_dev)
+{
+    API_BEGIN
+    dom_require(ctx);
+    if (!ctx->list_valid) throw HipError("md_dom_async_begin: no valid neighbour list (run the build sequence first)");
+    if (!flag_dev || !kuw_dev) throw HipError("md_dom_async_begin: flag and K/U/W device words are required");
+    if (nsteps < 0 || nsteps > 0x3fffffff) throw HipError("md_dom_async_begin: bad nsteps");
+    auto &d = ctx->dom;
+    hipStream_t st = ctx->stream;
+    d.flag_dev = (int32_t *)flag_dev;
+    d.kuw_dev = (double *)kuw_dev;
+    d.a_nvt = ensemble == MD_NVT;
+    d.a_nf = nf;
+    d.a_term1 = 0.0;
+    if (d.a_nvt) {
+        if (!ktemp || !r1 || !r2) throw HipError("md_dom_async_begin: NVT needs ktemp, r1, r2");
+        if (!(tau > 0.0) || !(nf > 0.0)) throw HipError("md_dom_async_begin: NVT needs tau > 0 and nf > 0");
+        ctx->d_kt.ensure(nsteps);
+        ctx->d_r1.ensure(nsteps);
+        ctx->d_r2.ensure(nsteps);
+        HIPCHK(hipMemcpyAsync(ctx->d_kt.p, ktemp, nsteps * sizeof(double), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(ctx->d_r1.p, r1, nsteps * sizeof(double), hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(ctx->d_r2.p, r2, nsteps * sizeof(double), hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st)); // the host arrays are borrowed for this call only
+        d.a_term1 = std::exp(-(dt / tau));
+    }
+    if (!d.a_nvt) k_set_scale<<<1, 1, 0, st>>>(ctx->scal.p, 1.0);
+    k_reset_viol<<<1, 1, 0, st>>>(ctx->scal.p);
+    HIPCHK(hipGetLastError());
+    API_END
+}
+
+// pending rescale, half-kick, drift, displacement check; halo coordinates packed; this rank's flag exported
+int md_dom_step_a(md_ctx *ctx, double dt, int step)
+{
+    API_BEGIN
+    auto &d = ctx->dom;
+    hipStream_t st = ctx->stream;
+    if (ctx->n > 0) launch_kickdrift(ctx, true, dt, true, step);
+    DevState s = ctx->dev(ctx->cur);
+    double shift_l = (d.rank == 0) ? ctx->L[0] : 0.0;
+    double shift_r = (d.rank == d.nranks - 1) ? -ctx->L[0] : 0.0;
+    for (int sd = 0; sd < 2; ++sd)
+        if (d.nsend_halo[sd] > 0)
+            k_dom_pack_pos<<<nblocks(d.nsend_halo[sd]), MD_BLOCK, 0, st>>>((int)d.nsend_halo[sd], d.send_slot[sd].p,
+                                                                          s.pos, sd ? shift_r : shift_l,
+                                                                          (d.ext_cap >= 3 * d.nsend_halo[sd]) ? d.ext_send[sd]
+                                                                                                              : d.sbuf[sd].p);
+    k_dom_flag_export<<<1, 1, 0, st>>>(ctx->scal.p, d.flag_dev);
+    HIPCHK(hipGetLastError());
+    API_END
+}
+
+// reduced flag adopted; neighbours' halo coordinates adopted; self-image ghosts; forces + second half-kick;
+// this rank's K (U, W) sums exported
+int md_dom_step_b(md_ctx *ctx, double dt, int step, int want_uw)
+{
+    API_BEGIN
+    auto &d = ctx->dom;
+    hipStream_t st = ctx->stream;
+    k_dom_flag_import<<<1, 1, 0, st>>>(ctx->scal.p, d.flag_dev);
+    DevState s = ctx->dev(ctx->cur);
+    int64_t off = 0;
+    for (int sd = 0; sd < 2; ++sd) {
+        if (d.nrecv_halo[sd] > 0)
+            k_dom_unpack_pos<<<nblocks(d.nrecv_halo[sd]), MD_BLOCK, 0, st>>>((int)d.nrecv_halo[sd], d.xh_slot.p + off,
+                                                                            (d.ext_cap >= 3 * d.nrecv_halo[sd])
+                                                                                ? d.ext_recv[sd]
+                                                                                : d.rbuf[sd].p,
+                                                                            s.pos);
+        off += d.nrecv_halo[sd];
+    }
+    launch_ghost_update(ctx, step);
+    if (ctx->n > 0) launch_force(ctx, want_uw != 0, true, dt, step);
+    k_dom_local_sums<<<1, 1024, 0, st>>>(ctx->n > 0 ? ctx->nblk : 0, ctx->partials.p, want_uw, d.kuw_dev, ctx->scal.p, step);
+    HIPCHK(hipGetLastError());
+    ctx->st_steps += 1;
+    API_END
+}
+
+// from the reduced sums: global K (U, W); Bussi scale of this step, applied by the next md_dom_step_a
+int md_dom_step_c(md_ctx *ctx, int step, int want_uw)
+{
+    API_BEGIN
+    auto &d = ctx->dom;
+    k_dom_global_finalize<<<1, 1, 0, ctx->stream>>>(d.kuw_dev, want_uw, d.a_nvt ? 1 : 0, d.a_nf, d.a_term1, ctx->d_kt.p,
+                                                    ctx->d_r1.p, ctx->d_r2.p, ctx->scal.p, step);
+    HIPCHK(hipGetLastError());
+    API_END
+}
+
+// waits for the window; first_viol = first step at which some rank's displacement check failed (or
+// 0x7fffffff); uwk = global {U, W, K} of the last executed step that reported them
+int md_dom_async_end(md_ctx *ctx, int apply_pending_scale, int32_t *first_viol, double *uwk)
+{
+    API_BEGIN
+    dom_require(ctx);
+    if (apply_pending_scale && ctx->dom.a_nvt && ctx->n > 0) {
+        // the last step's rescale (src/thermostat.jl:43-45) is still pending: apply it so that the state the
+        // host can download is the reference's.  Skipped by the kernel itself after a violation (the pending
+        // scale was then already consumed by the violating step's drift).
+        DevState sd = ctx->dev(ctx->cur);
+        if (ctx->dim == 3)
+            k_scale_v<3><<<ctx->nblk, MD_BLOCK, 0, ctx->stream>>>((int)ctx->n, sd, ctx->scal.p, 1.0, 2);
+        else
+            k_scale_v<2><<<ctx->nblk, MD_BLOCK, 0, ctx->stream>>>((int)ctx->n, sd, ctx->scal.p, 1.0, 2);
+        k_set_scale_unless_violated<<<1, 1, 0, ctx->stream>>>(ctx->scal.p, 1.0);
+    }
+    Scalars h = read_scalars(ctx);
+    if (first_viol) *first_viol = h.first_viol;
+    if (uwk) {
+        uwk[0] = h.U;
+        uwk[1] = h.W;
+        uwk[2] = h.K;
+    }
+    API_END
+}
+
+// ---------------------------------------------------------------------------------------------
+// Native transport: the window loop of the asynchronous scheme above entirely inside the library, the
+// collectives issued by the library itself (RCCL over xGMI) on the handle's stream -- no host work and no
+// stream hand-over between a step's kernels and its three small collectives.
+// ---------------------------------------------------------------------------------------------
+int md_dom_comm_unique_id(const char *rccl_path, void *id128)
+{
+    try {
+        if (!id128) throw std::runtime_error("md_dom_comm_unique_id: null output");
+        g_rccl.load(rccl_path);
+        ncclUniqueId id;
+        g_rccl.check(g_rccl.GetUniqueId(&id), "ncclGetUniqueId");
+        memcpy(id128, id.internal, NCCL_UNIQUE_ID_BYTES);
+        return 0;
+    } catch (const std::exception &e) {
+        return fail(nullptr, e.what());
+    }
+}
+
+int md_dom_comm_init(md_ctx *ctx, const char *rccl_path, const void *id128)
+{
+    API_BEGIN
+    dom_require(ctx);
+    if (!id128) throw HipError("md_dom_comm_init: null unique id");
+    auto &d = ctx->dom;
+    g_rccl.load(rccl_path);
+    if (d.comm) {
+        (void)g_rccl.CommDestroy(d.comm);
+        d.comm = nullptr;
+    }
+    ncclUniqueId id;
+    memcpy(id.internal, id128, NCCL_UNIQUE_ID_BYTES);
+    g_rccl.check(g_rccl.CommInitRank(&d.comm, d.nranks, id, d.rank), "ncclCommInitRank");
+    d.own_flag.alloc(4);
+    d.own_kuw.alloc(4);
+    // self-test: the sum of (rank + 1) over the ranks, and the minimum of (rank + 7)
+    hipStream_t st = ctx->stream;
+    double hv[3] = {(double)(d.rank + 1), 1.0, 0.0};
+    int32_t hf = d.rank + 7;
+    HIPCHK(hipMemcpyAsync(d.own_kuw.p, hv, sizeof hv, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(d.own_flag.p, &hf, sizeof hf, hipMemcpyHostToDevice, st));
+    g_rccl.check(g_rccl.AllReduce(d.own_kuw.p, d.own_kuw.p, 3, ncclFloat64, ncclSum, d.comm, st), "ncclAllReduce");
+    g_rccl.check(g_rccl.AllReduce(d.own_flag.p, d.own_flag.p, 1, ncclInt32, ncclMin, d.comm, st), "ncclAllReduce");
+    HIPCHK(hipMemcpyAsync(hv, d.own_kuw.p, sizeof hv, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&hf, d.own_flag.p, sizeof hf, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    double want = 0.5 * d.nranks * (d.nranks + 1.0);
+    if (hv[0] != want || hv[1] != (double)d.nranks || hf != 7)
+        throw HipError("md_dom_comm_init: RCCL self-test returned wrong values");
+    API_END
+}
+
+int md_dom_run_window(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, double tau, double nf, const double *ktemp,
+                      const double *r1, const double *r2, int report_last, int apply_pending_scale,
+                      int32_t *first_viol, double *uwk)
+{
+    API_BEGIN
+    dom_require(ctx);
+    auto &d = ctx->dom;
+    if (!d.comm) throw HipError("md_dom_run_window: no communicator (md_dom_comm_init first)");
+    int rc = md_dom_async_begin(ctx, nsteps, dt, ensemble, tau, nf, ktemp, r1, r2, d.own_flag.p, d.own_kuw.p);
+    if (rc != 0) return rc;
+    hipStream_t st = ctx->stream;
+    const int left = (d.rank + d.nranks - 1) % d.nranks, right = (d.rank + 1) % d.nranks;
+    const bool nvt = d.a_nvt;
+    for (int64_t t = 0; t < nsteps; ++t) {
+        int want = (report_last && t == nsteps - 1) ? 1 : 0;
+        rc = md_dom_step_a(ctx, dt, (int)t);
+        if (rc != 0) return rc;
+        g_rccl.check(g_rccl.AllReduce(d.flag_dev, d.flag_dev, 1, ncclInt32, ncclMin, d.comm, st), "ncclAllReduce(flag)");
+        // halo coordinates to the two ring neighbours.  With one or two ranks both neighbours are the same
+        // peer: messages between a pair match in issue order, and a rank's left-bound message is what its
+        // peer receives "from the right" -- hence receive-from-right is posted first.
+        double *sb[2], *rb[2];
+        for (int sd = 0; sd < 2; ++sd) {
+            sb[sd] = (d.ext_cap >= 3 * d.nsend_halo[sd]) ? d.ext_send[sd] : d.sbuf[sd].p;
+            rb[sd] = (d.ext_cap >= 3 * d.nrecv_halo[sd]) ? d.ext_recv[sd] : d.rbuf[sd].p;
+        }
+        g_rccl.check(g_rccl.GroupStart(), "ncclGroupStart");
+        if (d.nsend_halo[0] > 0) g_rccl.check(g_rccl.Send(sb[0], 3 * d.nsend_halo[0], ncclFloat64, left, d.comm, st), "ncclSend");
+        if (d.nsend_halo[1] > 0) g_rccl.check(g_rccl.Send(sb[1], 3 * d.nsend_halo[1], ncclFloat64, right, d.comm, st), "ncclSend");
+        if (d.nrecv_halo[1] > 0) g_rccl.check(g_rccl.Recv(rb[1], 3 * d.nrecv_halo[1], ncclFloat64, right, d.comm, st), "ncclRecv");
+        if (d.nrecv_halo[0] > 0) g_rccl.check(g_rccl.Recv(rb[0], 3 * d.nrecv_halo[0], ncclFloat64, left, d.comm, st), "ncclRecv");
+        g_rccl.check(g_rccl.GroupEnd(), "ncclGroupEnd");
+        rc = md_dom_step_b(ctx, dt, (int)t, want);
+        if (rc != 0) return rc;
+        if (nvt || want) {
+            g_rccl.check(g_rccl.AllReduce(d.kuw_dev, d.kuw_dev, 3, ncclFloat64, ncclSum, d.comm, st), "ncclAllReduce(K,U,W)");
+            rc = md_dom_step_c(ctx, (int)t, want);
+            if (rc != 0) return rc;
+        }
+    }
+    return md_dom_async_end(ctx, apply_pending_scale, first_viol, uwk);
     API_END
 }
 

@@ -13,6 +13,8 @@ ghost copies are fed by the two neighbour ranks instead of by periodic self-imag
 """
 import ctypes as C
 
+import os
+
 import numpy as np
 
 from . import _lib
@@ -125,6 +127,38 @@ class Exchanger:
             return float(t[0].item())
         return wait
 
+    # -- stream-ordered variants for the asynchronous step loop: no host wait under RCCL --------------
+    def allreduce_dev(self, t, op="sum"):
+        """In-place all-reduce of a device tensor.  RCCL: enqueued behind the current stream's work, nothing
+        waits on the host.  gloo (test mode): staged through the host."""
+        dist = self.dist
+        rop = {"sum": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN}[op]
+        if self.p2p_on_device:
+            dist.all_reduce(t, op=rop, group=self.group)
+        else:
+            c = t.cpu()
+            dist.all_reduce(c, op=rop, group=self.group)
+            t.copy_(c)
+
+    def sendrecv_dev(self, send_left, send_right, recv_left, recv_right):
+        """The neighbour exchange of sendrecv(), ordered on the current stream instead of waited for."""
+        if not self.p2p_on_device:
+            self.sendrecv(send_left, send_right, recv_left, recv_right)
+            return
+        dist = self.dist
+        ops = []
+        if send_left.numel():
+            ops.append(dist.P2POp(dist.isend, send_left, self.left, self.group))
+        if send_right.numel():
+            ops.append(dist.P2POp(dist.isend, send_right, self.right, self.group))
+        if recv_right.numel():
+            ops.append(dist.P2POp(dist.irecv, recv_right, self.right, self.group))
+        if recv_left.numel():
+            ops.append(dist.P2POp(dist.irecv, recv_left, self.left, self.group))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()   # (RCCL: makes the current stream wait, not the host)
+
     def allreduce(self, values, op="sum"):
         t = self.torch.tensor(values, dtype=self.torch.float64, device=self.coll_device)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM if op == "sum" else self.dist.ReduceOp.MAX,
@@ -143,8 +177,6 @@ class DomainDevice:
         self.ex = exchanger
         self.dim, self.n_global = int(dim), int(n_global)
         self.rank, self.nranks = exchanger.rank, exchanger.world
-        if self.nranks < 2:
-            raise ValueError("DomainDevice needs at least 2 ranks (use MDDevice on one GPU)")
         box = np.asarray(box, dtype=np.float64)
         if box.ndim == 0:
             box = np.eye(self.dim) * float(box)
@@ -344,6 +376,176 @@ class DomainDevice:
         self._chk(self._L.md_dom_forces(self._h, 0.0, 0, 1, uwk))
         U, W = self.ex.allreduce([uwk[0], uwk[1]])
         return U, W
+
+    # -- asynchronous step loop ---------------------------------------------------------------------
+    def _async_setup(self):
+        """Device words the ranks all-reduce every step, and the stream everything is ordered on."""
+        if getattr(self, "_flag", None) is not None:
+            return
+        ex = self.ex
+        torch = ex.torch
+        if not ex.on_device:
+            raise MdhipError("the asynchronous step loop needs device-resident exchange buffers "
+                             "(nccl backend, or MDHIP_DOM_STAGE=device under gloo)")
+        self._stream = torch.cuda.Stream(device=ex.device)
+        torch.cuda.current_stream(ex.device).synchronize()
+        self._chk(self._L.md_set_stream(self._h, C.c_void_p(self._stream.cuda_stream)))
+        with torch.cuda.stream(self._stream):
+            self._flag = torch.full((1,), 0x7FFFFFFF, dtype=torch.int32, device=ex.device)
+            self._kuw = torch.zeros(3, dtype=torch.float64, device=ex.device)
+        self._stream.synchronize()
+
+    def run_async(self, nsteps, dt, ensemble=_lib.MD_NVE, tau=0.0, nf=None, ktemp=None, r1=None, r2=None):
+        """run() without a host wait per step.  A window of steps (up to the next scheduled list build) is
+        enqueued on one stream: kernels of the library, the all-reduce (MIN) of the displacement flag, the
+        neighbour exchange of the halo coordinates and the all-reduce (SUM) of K/U/W alternate in stream order.
+        A violation on any rank at step m reaches every rank through the reduced flag before step m's force
+        evaluation, so all later kernels of the window skip themselves everywhere; the host reads the flag
+        once per window, rebuilds at the drifted positions and resumes -- the single-GPU scheme, globally.
+        Returns global (U, W, K) of the last step."""
+        self._async_setup()
+        torch = self.ex.torch
+        nf = float(self.dim * (self.n_global - 1.0)) if nf is None else float(nf)
+        nvt = ensemble == _lib.MD_NVT
+        dp = C.POINTER(C.c_double)
+        if nvt:
+            ktemp = np.ascontiguousarray(ktemp, dtype=np.float64)
+            r1 = np.ascontiguousarray(r1, dtype=np.float64)
+            r2 = np.ascontiguousarray(r2, dtype=np.float64)
+        uwk = (C.c_double * 3)()
+        fv = C.c_int32()
+        U = W = K = float("nan")
+        L, h = self._L, self._h
+        with torch.cuda.stream(self._stream):
+            if self.builds == 0:
+                self.build()
+            s = 0
+            while s < nsteps:
+                wlen = int(min(nsteps - s, max(1, self.target_interval - self.steps_since_build)))
+                arrs = [a[s:s + wlen].ctypes.data_as(dp) if nvt else None for a in (ktemp, r1, r2)]
+                self._chk(L.md_dom_async_begin(h, wlen, float(dt), int(ensemble), float(tau), nf, *arrs,
+                                               C.c_void_p(self._flag.data_ptr()), C.c_void_p(self._kuw.data_ptr())))
+                sl, sr, rl, rr = self._zbufs
+                ns, nr = self._nsend_halo, self._nrecv_halo
+                sl, sr = sl[: ns[0] * POS_REC], sr[: ns[1] * POS_REC]
+                rl, rr = rl[: nr[0] * POS_REC], rr[: nr[1] * POS_REC]
+                ends_run = s + wlen == nsteps
+                for t in range(wlen):
+                    last = ends_run and t == wlen - 1
+                    self._chk(L.md_dom_step_a(h, float(dt), t))
+                    self.ex.allreduce_dev(self._flag, "min")
+                    self.ex.sendrecv_dev(sl, sr, rl, rr)
+                    self._chk(L.md_dom_step_b(h, float(dt), t, 1 if last else 0))
+                    if nvt or last:
+                        self.ex.allreduce_dev(self._kuw, "sum")
+                        self._chk(L.md_dom_step_c(h, t, 1 if last else 0))
+                self._chk(L.md_dom_async_end(h, 1 if ends_run else 0, C.byref(fv), uwk))
+                if fv.value < wlen:
+                    # step m's drift left the rows' validity radius on some rank: every rank holds the drifted
+                    # positions and skipped everything after; rebuild there and redo the force half of step m
+                    m = int(fv.value)
+                    g = s + m
+                    last = g == nsteps - 1
+                    self.violations += 1
+                    observed = self.steps_since_build + m + 1
+                    self.target_interval = max(2, (observed * 4) // 5)
+                    self.build()
+                    self._chk(L.md_dom_forces(h, float(dt), 1, 1 if last else 0, uwk))
+                    if nvt or last:
+                        U, W, K = self.ex.allreduce([uwk[0], uwk[1], uwk[2]])
+                    if nvt:
+                        scale = float(bussi_scale(K, ktemp[g], nf, dt, tau, r1[g], r2[g]))
+                        K = K * scale * scale
+                        if last:
+                            self._chk(L.md_scale_velocities(h, scale))
+                        else:
+                            self._chk(L.md_dom_set_scale(h, scale))
+                    s = g + 1
+                else:
+                    self.steps_since_build += wlen
+                    s += wlen
+                    if ends_run:
+                        U, W, K = uwk[0], uwk[1], uwk[2]
+                    elif self.steps_since_build >= self.target_interval:
+                        self.build()
+                        self.target_interval += 1
+        return U, W, K
+
+    # -- native transport: the window loop inside the library, RCCL issued by the library ----------------
+    def _native_setup(self):
+        if getattr(self, "_native_ready", False):
+            return
+        ex = self.ex
+        torch = ex.torch
+        if not ex.p2p_on_device:
+            raise MdhipError("the native step loop needs one GPU per rank (RCCL); use run_async/run under gloo")
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        path_b = path.encode() if os.path.exists(path) else None
+        ident = torch.zeros(128, dtype=torch.uint8)
+        if self.rank == 0:
+            buf = (C.c_ubyte * 128)()
+            if self._L.md_dom_comm_unique_id(path_b, buf) != 0:
+                raise MdhipError(self._L.md_last_error(None).decode())
+            ident = torch.tensor(list(buf), dtype=torch.uint8)
+        ident = ident.to(ex.coll_device)
+        ex.dist.broadcast(ident, src=ex.dist.get_global_rank(ex.group, 0) if ex.group is not None else 0, group=ex.group)
+        raw = bytes(ident.cpu().tolist())
+        self._chk(self._L.md_dom_comm_init(self._h, path_b, C.c_char_p(raw)))
+        self._native_ready = True
+
+    def run_native(self, nsteps, dt, ensemble=_lib.MD_NVE, tau=0.0, nf=None, ktemp=None, r1=None, r2=None):
+        """run_async() with the window loop inside the library (md_dom_run_window): one C call per window,
+        RCCL issued by the library on its own stream.  List builds (every ~25 steps) still go through
+        torch.distributed.  Returns global (U, W, K) of the last step."""
+        self._native_setup()
+        nf = float(self.dim * (self.n_global - 1.0)) if nf is None else float(nf)
+        nvt = ensemble == _lib.MD_NVT
+        dp = C.POINTER(C.c_double)
+        if nvt:
+            ktemp = np.ascontiguousarray(ktemp, dtype=np.float64)
+            r1 = np.ascontiguousarray(r1, dtype=np.float64)
+            r2 = np.ascontiguousarray(r2, dtype=np.float64)
+        uwk = (C.c_double * 3)()
+        fv = C.c_int32()
+        U = W = K = float("nan")
+        L, h = self._L, self._h
+        if self.builds == 0:
+            self.build()
+        s = 0
+        while s < nsteps:
+            wlen = int(min(nsteps - s, max(1, self.target_interval - self.steps_since_build)))
+            arrs = [a[s:s + wlen].ctypes.data_as(dp) if nvt else None for a in (ktemp, r1, r2)]
+            ends_run = s + wlen == nsteps
+            self._chk(L.md_dom_run_window(h, wlen, float(dt), int(ensemble), float(tau), nf, *arrs,
+                                          1 if ends_run else 0, 1 if ends_run else 0, C.byref(fv), uwk))
+            if fv.value < wlen:
+                m = int(fv.value)
+                g = s + m
+                last = g == nsteps - 1
+                self.violations += 1
+                observed = self.steps_since_build + m + 1
+                self.target_interval = max(2, (observed * 4) // 5)
+                self.build()
+                self._chk(L.md_dom_forces(h, float(dt), 1, 1 if last else 0, uwk))
+                if nvt or last:
+                    U, W, K = self.ex.allreduce([uwk[0], uwk[1], uwk[2]])
+                if nvt:
+                    scale = float(bussi_scale(K, ktemp[g], nf, dt, tau, r1[g], r2[g]))
+                    K = K * scale * scale
+                    if last:
+                        self._chk(L.md_scale_velocities(h, scale))
+                    else:
+                        self._chk(L.md_dom_set_scale(h, scale))
+                s = g + 1
+            else:
+                self.steps_since_build += wlen
+                s += wlen
+                if ends_run:
+                    U, W, K = uwk[0], uwk[1], uwk[2]
+                elif self.steps_since_build >= self.target_interval:
+                    self.build()
+                    self.target_interval += 1
+        return U, W, K
 
     def run(self, nsteps, dt, ensemble=_lib.MD_NVE, tau=0.0, nf=None, ktemp=None, r1=None, r2=None):
         """The step loop of run_simulation! across the slabs; returns global (U, W, K) of the last step.

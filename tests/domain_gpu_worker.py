@@ -1,5 +1,5 @@
 """Worker for tests/test_domain_gpu.py: launched by torch.distributed.run with N ranks that all use GPU 0
-(gloo transport, host staging).  Compares the slab-decomposed run with a single-handle run of the same
+(gloo transport, host staging; or RCCL with a single rank whose two x-neighbours are itself).  Compares the slab-decomposed run with a single-handle run of the same
 system (rank 0) and, for forces, with the CPU oracle."""
 import os
 import sys
@@ -16,7 +16,11 @@ def main():
     from moleculardynamics.jl_amd.domain import DomainDevice, Exchanger
     from tests.util import lj_system
 
-    dist.init_process_group(backend="gloo")
+    backend = os.environ.get("DOM_BACKEND", "gloo")   # "nccl" (= RCCL) only with one rank per GPU: world size 1 on the test box
+    if backend == "nccl":
+        import torch
+        torch.cuda.set_device(0)
+    dist.init_process_group(backend=backend)
     rank, world = dist.get_rank(), dist.get_world_size()
     n = int(os.environ.get("DOM_N", "8000"))
     kT = float(os.environ.get("DOM_KT", "2.0"))
@@ -38,7 +42,8 @@ def main():
         X0, V0, F0, I0 = d.gather_global()
         d.upload_global(s["x"], s["v"], s["f"], s["img"], s["diam"])
         d.builds = 0
-        Ue, We, Ke = d.run(nsteps, 0.002, ens, 0.1, nf, kt, r1, r2)
+        runner = {"0": d.run, "1": d.run_async, "native": d.run_native}[os.environ.get("DOM_ASYNC", "0")]
+        Ue, We, Ke = runner(nsteps, 0.002, ens, 0.1, nf, kt, r1, r2)
         X, V, F, IM = d.gather_global()
         stats = (d.builds, d.violations, d.counts())
     ok = True

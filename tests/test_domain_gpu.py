@@ -23,10 +23,23 @@ def _launch(nproc, env_extra, port):
     assert r.returncode == 0, "slab-decomposed run disagrees with the single-handle run"
 
 
-@pytest.mark.parametrize("nproc,nvt,stage", [(2, 0, ""), (3, 0, ""), (2, 1, ""), (2, 0, "device")])
-def test_slab_decomposition_matches_single_gpu(nproc, nvt, stage):
+@pytest.mark.parametrize("nproc,nvt,stage,mode", [
+    (2, 0, "", "sync"), (3, 0, "", "sync"), (2, 1, "", "sync"), (2, 0, "device", "sync"),
+    # the asynchronous step loop (no host wait per step; flags and K/U/W all-reduced on the device)
+    (2, 0, "device", "async"), (2, 1, "device", "async"), (3, 1, "device", "async"),
+    # the real RCCL transport, one rank whose left and right neighbours are itself: stream-ordered
+    # collectives and self send/recv between the library's kernels
+    (1, 1, "", "nccl-sync"), (1, 0, "", "nccl-async"), (1, 1, "", "nccl-async"),
+    # the native transport: window loop inside the library, RCCL called by the library itself
+    (1, 0, "", "nccl-native"), (1, 1, "", "nccl-native"),
+])
+def test_slab_decomposition_matches_single_gpu(nproc, nvt, stage, mode):
     # N=8000 -> L=20.7: 2 slabs of 10.4, 3 slabs of 6.9 (>= 2 cells each); kT=2 and dt=0.002 make
     # particles migrate between slabs and cross the periodic faces within the run
     # stage == "device": exchange buffers live on the GPU (the RCCL-path plumbing) although gloo carries them
-    _launch(nproc, {"DOM_N": "8000", "DOM_KT": "2.0", "DOM_STEPS": "60", "DOM_NVT": str(nvt), "MDHIP_DOM_STAGE": stage},
-            29511 + nproc + 10 * nvt + (20 if stage else 0))
+    env = {"DOM_N": "8000", "DOM_KT": "2.0", "DOM_STEPS": "60", "DOM_NVT": str(nvt), "MDHIP_DOM_STAGE": stage,
+           "DOM_ASYNC": "native" if mode.endswith("native") else ("1" if mode.endswith("async") else "0"),
+           "DOM_BACKEND": "nccl" if mode.startswith("nccl") else "gloo"}
+    port = 29511 + nproc + 10 * nvt + (20 if stage else 0) + {"sync": 0, "async": 40, "nccl-sync": 80, "nccl-async": 120,
+                                                                "nccl-native": 160}[mode]
+    _launch(nproc, env, port)
