@@ -164,15 +164,6 @@ def main():
         nf = 3.0 * (n_global - 1.0)
         dev = DomainDevice(3, n_global, gbox, 2.5, ex, device_id=local_rank, n_cap=int(1.3 * a.n) + 8192)
         dev.set_potential(_lib.MD_POT_LJ, [1.0, 1.0, 2.5])
-        if a.skin is not None:
-            dev.set_skin(a.skin)
-        xg = inp["x"].copy()
-        xg[:, 0] += rank * L1
-        ids = (rank * a.n + np.arange(a.n)).astype(np.int32)
-        dev.set_uniform(True, 1.0)
-        dev.upload_local(ids, xg, inp["v"], inp["f"], inp["img"], inp["diam"])
-        rng = np.random.default_rng(4242)      # the same stream on every rank: identical thermostat noise
-
         # step loop (MDHIP_DOM_LOOP): "native" = windows of steps inside the library, RCCL issued by the library
         # (default with one GPU per rank); "async" = the same scheme driven from Python through
         # torch.distributed, stream-ordered; "sync" = one host round trip per phase (host-staged gloo runs)
@@ -181,6 +172,17 @@ def main():
             loop = "sync"
         stepper = {"sync": dev.run, "async": dev.run_async, "native": dev.run_native}[loop]
         sync_loop = loop == "sync"
+
+        if a.skin is not None:
+            dev.set_skin(a.skin)
+        elif loop == "native" and os.environ.get("MDHIP_DOM_PRUNE", "1") == "1":
+            dev.enable_pruning()           # skin 0.6 + inner rows 0.16, prune steps scheduled inside the windows
+        xg = inp["x"].copy()
+        xg[:, 0] += rank * L1
+        ids = (rank * a.n + np.arange(a.n)).astype(np.int32)
+        dev.set_uniform(True, 1.0)
+        dev.upload_local(ids, xg, inp["v"], inp["f"], inp["img"], inp["diam"])
+        rng = np.random.default_rng(4242)      # the same stream on every rank: identical thermostat noise
 
         def run(nsteps, thermo=False):
             if nsteps <= 0:
@@ -240,7 +242,7 @@ def main():
             "parallelism": "1 GPU" if not use_domain else f"{world}-way 1-D slab decomposition along x, halo exchange every "
                                                             f"step over torch.distributed ({dist.get_backend()}), "
                                                             f"step loop: {loop}",
-            "skin": a.skin if a.skin is not None else (0.4 if use_domain else 0.6),
+            "skin": a.skin if a.skin is not None else (0.6 if (not use_domain or st1["prunes"] > 0) else 0.4),
             "rebuilds_in_timed_region": st1["rebuilds"] - st0["rebuilds"],
             "global_particles": total_particles,
             "avg_list_candidates": st1["avg_neighbors"],

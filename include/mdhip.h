@@ -201,7 +201,18 @@ int md_dom_comm_unique_id(const char *rccl_path, void *id128);
 int md_dom_comm_init(md_ctx *ctx, const char *rccl_path, const void *id128);
 int md_dom_run_window(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, double tau, double nf, const double *ktemp,
                       const double *r1, const double *r2, int report_last, int apply_pending_scale,
-                      int32_t *first_viol, double *uwk);
+                      int64_t prune_interval, int32_t *first_viol, double *uwk, double *info /* [6] or NULL */);
+/* Inner rows (see md_set_inner_skin) on a slab handle.  Every rank must prune at the same steps, so the caller
+ * plans the schedule from all-reduced quantities: prune_interval = steps between prune steps inside a window
+ * (0 = none scheduled); info returns {1 if the violating step was a prune step, this rank's d1 = max|x - x0| at
+ * the last executed prune step, steps since the build at that prune step or -1, 1 if pruning is active,
+ * effective skin, effective inner skin}.
+ * After a violation: all-reduce(MAX) md_dom_max_disp0; if the outer rows still hold (d0 + inner_skin/2 <=
+ * skin/2 and the violating step was not a prune step) call md_dom_invalidate_inner, else rebuild; then
+ * md_dom_forces for the violating step.                                                                  */
+int md_dom_enable_pruning(md_ctx *ctx, int on);
+int md_dom_max_disp0(md_ctx *ctx, double *d0);
+int md_dom_invalidate_inner(md_ctx *ctx);
 
 /* Library build info: returns e.g. "mdhip 0.1 gfx950". */
 const char *md_version(void);

@@ -23,6 +23,7 @@ EXPORTS = [
     "md_dom_put_recvbuf", "md_dom_set_step_buffers", "md_dom_step_begin", "md_dom_step_end", "md_dom_forces", "md_dom_set_scale",
     "md_dom_counts", "md_set_stream", "md_dom_async_begin", "md_dom_step_a", "md_dom_step_b", "md_dom_step_c",
     "md_dom_async_end", "md_dom_comm_unique_id", "md_dom_comm_init", "md_dom_run_window",
+    "md_dom_enable_pruning", "md_dom_max_disp0", "md_dom_invalidate_inner",
 ]
 
 
@@ -113,7 +114,10 @@ def load():
     L.md_dom_comm_unique_id.argtypes = [C.c_char_p, C.c_void_p]
     L.md_dom_comm_init.argtypes = [vp, C.c_char_p, C.c_void_p]
     L.md_dom_run_window.argtypes = [vp, C.c_int64, C.c_double, C.c_int, C.c_double, C.c_double, dp, dp, dp, C.c_int, C.c_int,
-                                    C.POINTER(C.c_int32), dp]
+                                    C.c_int64, C.POINTER(C.c_int32), dp, dp]
+    L.md_dom_enable_pruning.argtypes = [vp, C.c_int]
+    L.md_dom_max_disp0.argtypes = [vp, dp]
+    L.md_dom_invalidate_inner.argtypes = [vp]
     for name in EXPORTS:
         if name.startswith("md_dom_") or name in ("md_create_domain", "md_set_stream"):
             getattr(L, name).restype = C.c_int

@@ -187,6 +187,45 @@ __global__ void __launch_bounds__(MD_BLOCK)
     pos[k] = p;
 }
 
+// both sides in one launch (asynchronous stepping), plus this rank's displacement flag for the all-reduce
+__global__ void __launch_bounds__(MD_BLOCK)
+    k_dom_pack_pos2(int n0, int n1, const int32_t *__restrict__ slot0, const int32_t *__restrict__ slot1,
+                    const double4 *__restrict__ pos, double shift0, double shift1, double *__restrict__ out0,
+                    double *__restrict__ out1, const Scalars *sc, int32_t *flag)
+{
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j == 0 && flag) flag[0] = sc->first_viol;
+    if (j < n0) {
+        double4 p = pos[slot0[j]];
+        out0[3 * (size_t)j + 0] = p.x + shift0;
+        out0[3 * (size_t)j + 1] = p.y;
+        out0[3 * (size_t)j + 2] = p.z;
+    } else if (j < n0 + n1) {
+        j -= n0;
+        double4 p = pos[slot1[j]];
+        out1[3 * (size_t)j + 0] = p.x + shift1;
+        out1[3 * (size_t)j + 1] = p.y;
+        out1[3 * (size_t)j + 2] = p.z;
+    }
+}
+
+// both sides in one launch, plus adoption of the all-reduced flag (kernels launched after this one see it)
+__global__ void __launch_bounds__(MD_BLOCK)
+    k_dom_unpack_pos2(int n0, int n1, const int32_t *__restrict__ slot, const double *__restrict__ in0,
+                      const double *__restrict__ in1, double4 *__restrict__ pos, Scalars *sc, const int32_t *flag)
+{
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j == 0 && flag && flag[0] < sc->first_viol) sc->first_viol = flag[0];
+    if (j >= n0 + n1) return;
+    const double *in = j < n0 ? in0 + 3 * (size_t)j : in1 + 3 * (size_t)(j - n0);
+    int k = slot[j];
+    double4 p = pos[k];
+    p.x = in[0];
+    p.y = in[1];
+    p.z = in[2];
+    pos[k] = p;
+}
+
 // local-order transfer (slab handles exchange per-rank particle sets with the host)
 template <int D>
 __global__ void __launch_bounds__(MD_BLOCK)
@@ -241,12 +280,6 @@ __global__ void k_reset_viol(Scalars *sc) { sc->first_viol = MD_NO_VIOLATION; }
 // ------------------------------------------------------------------------------------------
 // asynchronous stepping: the words the caller all-reduces between the phases of a step
 // ------------------------------------------------------------------------------------------
-__global__ void k_dom_flag_export(const Scalars *sc, int32_t *flag) { flag[0] = sc->first_viol; }
-__global__ void k_dom_flag_import(Scalars *sc, const int32_t *flag)
-{
-    if (flag[0] < sc->first_viol) sc->first_viol = flag[0];
-}
-
 // this rank's fixed-order sums of the force kernel's per-block partials: out = {sum v^2, sum u, sum w}
 __global__ void __launch_bounds__(1024)
     k_dom_local_sums(int nblk, const double *__restrict__ partials, int want_uw, double *__restrict__ out,

@@ -109,6 +109,7 @@ struct md_ctx {
         double a_nf = 0.0, a_term1 = 0.0;
         // native transport (md_dom_comm_init): RCCL called by the library on the handle's stream
         ncclComm_t comm = nullptr;
+        bool prune_enabled = false; // inner rows on a slab handle: the caller plans the (globally identical) schedule
         DBuf<int32_t> own_flag;
         DBuf<double> own_kuw;
     } dom;
@@ -548,16 +549,18 @@ void rebuild_t(md_ctx *c)
             set_tiles(h);
         }
     }
-    // single-GPU tiled path: ghosts become (owner, shift) references resolved while staging the halo, and the
-    // per-step ghost refresh disappears.  (Slab decomposition keeps real ghost records: they arrive by message.)
-    c->virtual_ghosts = c->use_tiles && !c->dom.on && c->cap < (1ll << 26);
+    // tiled path: periodic self-image ghosts become (owner, shift) references resolved while staging the halo,
+    // and the per-step ghost refresh disappears.  (Under slab decomposition the owner may itself be a received
+    // x-halo record: those are real records, refreshed by message, and reference themselves with shift 0.)
+    c->virtual_ghosts = c->use_tiles && c->cap < (1ll << 26);
     if (c->virtual_ghosts && nghost > 0)
         k_halo_virtualize<<<c->nblk, MD_BLOCK, 0, st>>>(n, c->halo.p, c->hcap, c->halo_count.p, c->gowner.p, c->gcode.p);
     c->list_valid = true;
     c->steps_since_build = 0;
     c->st_rebuilds++;
     c->inner_valid = false; // the next force evaluation is a prune step
-    c->prune_on = c->use_tiles && !c->dom.on && c->skin > 0.0 && c->inner_skin_req > 0.0 &&
+    // (a slab handle prunes only when its caller schedules prune steps: md_dom_enable_pruning)
+    c->prune_on = c->use_tiles && (!c->dom.on || c->dom.prune_enabled) && c->skin > 0.0 && c->inner_skin_req > 0.0 &&
                   c->inner_skin_req < 0.9 * c->skin && c->pot_kind != POT_CUSTOM;
     if (c->prune_on) {
         c->inner_skin = c->inner_skin_req;
@@ -1838,6 +1841,7 @@ int md_dom_forces(md_ctx *ctx, double dt, int kick, int want_uw, double *uwk)
         launch_force(ctx, want_uw != 0, kick != 0, dt, -1);
         launch_finalize(ctx, want_uw != 0, false, 1.0, 0.0, -1);
     }
+    if (kick) ctx->steps_since_prune += 1; // the force half of a step
     HIPCHK(hipGetLastError());
     Scalars h = read_scalars(ctx);
     if (uwk) {
@@ -1909,13 +1913,12 @@ int md_dom_step_a(md_ctx *ctx, double dt, int step)
     DevState s = ctx->dev(ctx->cur);
     double shift_l = (d.rank == 0) ? ctx->L[0] : 0.0;
     double shift_r = (d.rank == d.nranks - 1) ? -ctx->L[0] : 0.0;
-    for (int sd = 0; sd < 2; ++sd)
-        if (d.nsend_halo[sd] > 0)
-            k_dom_pack_pos<<<nblocks(d.nsend_halo[sd]), MD_BLOCK, 0, st>>>((int)d.nsend_halo[sd], d.send_slot[sd].p,
-                                                                          s.pos, sd ? shift_r : shift_l,
-                                                                          (d.ext_cap >= 3 * d.nsend_halo[sd]) ? d.ext_send[sd]
-                                                                                                              : d.sbuf[sd].p);
-    k_dom_flag_export<<<1, 1, 0, st>>>(ctx->scal.p, d.flag_dev);
+    double *out[2];
+    for (int sd = 0; sd < 2; ++sd) out[sd] = (d.ext_cap >= 3 * d.nsend_halo[sd]) ? d.ext_send[sd] : d.sbuf[sd].p;
+    int n0 = (int)d.nsend_halo[0], n1 = (int)d.nsend_halo[1];
+    k_dom_pack_pos2<<<nblocks(std::max(n0 + n1, 1)), MD_BLOCK, 0, st>>>(n0, n1, d.send_slot[0].p, d.send_slot[1].p, s.pos,
+                                                                        shift_l, shift_r, out[0], out[1], ctx->scal.p,
+                                                                        d.flag_dev);
     HIPCHK(hipGetLastError());
     API_END
 }
@@ -1927,19 +1930,13 @@ int md_dom_step_b(md_ctx *ctx, double dt, int step, int want_uw)
     API_BEGIN
     auto &d = ctx->dom;
     hipStream_t st = ctx->stream;
-    k_dom_flag_import<<<1, 1, 0, st>>>(ctx->scal.p, d.flag_dev);
     DevState s = ctx->dev(ctx->cur);
-    int64_t off = 0;
-    for (int sd = 0; sd < 2; ++sd) {
-        if (d.nrecv_halo[sd] > 0)
-            k_dom_unpack_pos<<<nblocks(d.nrecv_halo[sd]), MD_BLOCK, 0, st>>>((int)d.nrecv_halo[sd], d.xh_slot.p + off,
-                                                                            (d.ext_cap >= 3 * d.nrecv_halo[sd])
-                                                                                ? d.ext_recv[sd]
-                                                                                : d.rbuf[sd].p,
-                                                                            s.pos);
-        off += d.nrecv_halo[sd];
-    }
-    launch_ghost_update(ctx, step);
+    double *in[2];
+    for (int sd = 0; sd < 2; ++sd) in[sd] = (d.ext_cap >= 3 * d.nrecv_halo[sd]) ? d.ext_recv[sd] : d.rbuf[sd].p;
+    int n0 = (int)d.nrecv_halo[0], n1 = (int)d.nrecv_halo[1];
+    k_dom_unpack_pos2<<<nblocks(std::max(n0 + n1, 1)), MD_BLOCK, 0, st>>>(n0, n1, d.xh_slot.p, in[0], in[1], s.pos,
+                                                                          ctx->scal.p, d.flag_dev);
+    launch_ghost_update(ctx, step); // (nothing to do with virtual ghosts)
     if (ctx->n > 0) launch_force(ctx, want_uw != 0, true, dt, step);
     k_dom_local_sums<<<1, 1024, 0, st>>>(ctx->n > 0 ? ctx->nblk : 0, ctx->partials.p, want_uw, d.kuw_dev, ctx->scal.p, step);
     HIPCHK(hipGetLastError());
@@ -2037,9 +2034,51 @@ int md_dom_comm_init(md_ctx *ctx, const char *rccl_path, const void *id128)
     API_END
 }
 
+int md_dom_enable_pruning(md_ctx *ctx, int on)
+{
+    API_BEGIN
+    dom_require(ctx);
+    ctx->dom.prune_enabled = on != 0;
+    ctx->list_valid = false;
+    API_END
+}
+
+// this rank's largest displacement since the list build, max_i |x_i - x0_i| (exact; waits for the device)
+int md_dom_max_disp0(md_ctx *ctx, double *d0)
+{
+    API_BEGIN
+    dom_require(ctx);
+    hipStream_t st = ctx->stream;
+    k_reset_disp0<<<1, 1, 0, st>>>(ctx->scal.p);
+    if (ctx->n > 0) {
+        DevState sd = ctx->dev(ctx->cur);
+        if (ctx->dim == 3)
+            k_max_disp0<3><<<ctx->nblk, MD_BLOCK, 0, st>>>((int)ctx->n, sd, ctx->scal.p);
+        else
+            k_max_disp0<2><<<ctx->nblk, MD_BLOCK, 0, st>>>((int)ctx->n, sd, ctx->scal.p);
+    }
+    Scalars h = read_scalars(ctx);
+    double d0sq;
+    unsigned long long bits = h.max_disp2_bits;
+    memcpy(&d0sq, &bits, sizeof d0sq);
+    if (d0) *d0 = std::sqrt(d0sq);
+    API_END
+}
+
+// the next force evaluation refreshes the inner rows (a prune step) -- after a violation of the inner rows'
+// criterion that the outer rows survived
+int md_dom_invalidate_inner(md_ctx *ctx)
+{
+    API_BEGIN
+    dom_require(ctx);
+    ctx->inner_valid = false;
+    k_reset_viol<<<1, 1, 0, ctx->stream>>>(ctx->scal.p);
+    API_END
+}
+
 int md_dom_run_window(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, double tau, double nf, const double *ktemp,
                       const double *r1, const double *r2, int report_last, int apply_pending_scale,
-                      int32_t *first_viol, double *uwk)
+                      int64_t prune_interval, int32_t *first_viol, double *uwk, double *info)
 {
     API_BEGIN
     dom_require(ctx);
@@ -2050,8 +2089,14 @@ int md_dom_run_window(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, doub
     hipStream_t st = ctx->stream;
     const int left = (d.rank + d.nranks - 1) % d.nranks, right = (d.rank + 1) % d.nranks;
     const bool nvt = d.a_nvt;
+    const int64_t b0 = ctx->steps_since_build;
+    std::vector<int> prune_steps;
     for (int64_t t = 0; t < nsteps; ++t) {
         int want = (report_last && t == nsteps - 1) ? 1 : 0;
+        // inner rows: the schedule (identical on every rank) comes from the caller
+        if (ctx->prune_on && ctx->inner_valid && prune_interval > 0 && ctx->steps_since_prune >= prune_interval)
+            ctx->inner_valid = false;
+        if (ctx->prune_on && !ctx->inner_valid) prune_steps.push_back((int)t);
         rc = md_dom_step_a(ctx, dt, (int)t);
         if (rc != 0) return rc;
         g_rccl.check(g_rccl.AllReduce(d.flag_dev, d.flag_dev, 1, ncclInt32, ncclMin, d.comm, st), "ncclAllReduce(flag)");
@@ -2076,8 +2121,34 @@ int md_dom_run_window(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, doub
             rc = md_dom_step_c(ctx, (int)t, want);
             if (rc != 0) return rc;
         }
+        ctx->steps_since_prune += 1;
     }
-    return md_dom_async_end(ctx, apply_pending_scale, first_viol, uwk);
+    int32_t fv = MD_NO_VIOLATION;
+    rc = md_dom_async_end(ctx, apply_pending_scale, &fv, uwk);
+    if (rc != 0) return rc;
+    if (first_viol) *first_viol = fv;
+    // bookkeeping + what the caller's planner needs: info = {violating step was a prune step, this rank's d1 =
+    // max |x - x0| at the last executed prune step, steps since the build at that prune step (-1: none)}
+    int64_t done = fv < nsteps ? (int64_t)fv + 1 : nsteps; // steps whose drift was executed
+    ctx->steps_since_build = b0 + done;
+    bool was_prune = false;
+    int last_prune = -1;
+    for (int p : prune_steps) {
+        if (p == fv) was_prune = true;
+        if (p < fv && p < nsteps) last_prune = p;
+    }
+    if (info) {
+        Scalars h = read_scalars(ctx);
+        double d12;
+        unsigned long long bits = h.d1max2_bits;
+        memcpy(&d12, &bits, sizeof d12);
+        info[0] = was_prune ? 1.0 : 0.0;
+        info[1] = std::sqrt(d12);
+        info[2] = last_prune >= 0 ? (double)(b0 + last_prune + 1) : -1.0;
+        info[3] = ctx->prune_on ? 1.0 : 0.0;
+        info[4] = ctx->skin;
+        info[5] = ctx->prune_on ? ctx->inner_skin : 0.0;
+    }
     API_END
 }
 

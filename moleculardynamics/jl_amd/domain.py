@@ -21,6 +21,8 @@ from . import _lib
 from ._lib import MdhipError
 from .thermostat import bussi_scale
 
+_BUILD_TIMING = os.environ.get("MDHIP_DOM_TIMING", "0") == "1"   # print the phases of every list build (rank 0)
+
 MIG_REC, HALO_REC, POS_REC = 14, 5, 3
 
 
@@ -355,18 +357,29 @@ class DomainDevice:
 
     # -- list build -----------------------------------------------------------------------------
     def build(self):
+        import time
+        tm = [time.perf_counter()] if _BUILD_TIMING else None
+
+        def lap():
+            if tm is not None:
+                tm.append(time.perf_counter())
+
         ns = (C.c_int64 * 2)()
-        self._chk(self._L.md_dom_migrate_pack(self._h, ns))
-        nrecv = self._exchange((ns[0], ns[1]), MIG_REC)
-        self._chk(self._L.md_dom_migrate_unpack(self._h, (C.c_int64 * 2)(*nrecv)))
-        self._chk(self._L.md_dom_halo_pack(self._h, ns))
+        self._chk(self._L.md_dom_migrate_pack(self._h, ns)); lap()
+        nrecv = self._exchange((ns[0], ns[1]), MIG_REC); lap()
+        self._chk(self._L.md_dom_migrate_unpack(self._h, (C.c_int64 * 2)(*nrecv))); lap()
+        self._chk(self._L.md_dom_halo_pack(self._h, ns)); lap()
         self._nsend_halo = (ns[0], ns[1])
-        self._nrecv_halo = self._exchange(self._nsend_halo, HALO_REC)
-        self._chk(self._L.md_dom_halo_unpack(self._h, (C.c_int64 * 2)(*self._nrecv_halo)))
-        self._chk(self._L.md_dom_build(self._h))
-        self._bind_step_buffers()
+        self._nrecv_halo = self._exchange(self._nsend_halo, HALO_REC); lap()
+        self._chk(self._L.md_dom_halo_unpack(self._h, (C.c_int64 * 2)(*self._nrecv_halo))); lap()
+        self._chk(self._L.md_dom_build(self._h)); lap()
+        self._bind_step_buffers(); lap()
         self.steps_since_build = 0
         self.builds += 1
+        if tm is not None and self.rank == 0:
+            names = ("migrate_pack", "exchange", "migrate_unpack", "halo_pack", "exchange", "halo_unpack", "build", "bind")
+            print("[dom build] " + " ".join(f"{n}={1e6 * (b - a):.0f}us" for n, a, b in zip(names, tm, tm[1:]))
+                  + f" total={1e6 * (tm[-1] - tm[0]):.0f}us", flush=True)
 
     # -- forces / steps -------------------------------------------------------------------------
     def compute_forces(self):
@@ -493,10 +506,39 @@ class DomainDevice:
         self._chk(self._L.md_dom_comm_init(self._h, path_b, C.c_char_p(raw)))
         self._native_ready = True
 
+    def enable_pruning(self, skin=0.6, inner_skin=0.16):
+        """Inner rows on the slab handle (run_native schedules the prune steps): skin 0.6 / inner skin 0.16 are
+        the measured optimum for LJ r_c = 2.5.  Call before the first list build."""
+        self._chk(self._L.md_dom_enable_pruning(self._h, 1))
+        self._chk(self._L.md_set_skin(self._h, float(skin)))
+        self._chk(self._L.md_set_inner_skin(self._h, float(inner_skin)))
+        self._prune_req = True
+
+    def _plan(self, skin, inner):
+        """Rebuild interval R and prune interval L from the measured growth rate of the largest displacement
+        (the planner of md_run, csrc/mdhip.hip; a slab list build costs ~15 prune steps)."""
+        r = max(self._rate, 1e-12)
+        rmax = int(min(max(np.floor(self._safety * 0.5 * skin / r) + 1.0, 2.0), 4096.0))
+        lmax = int(min(max(np.floor(self._safety * 0.5 * inner / (1.1 * r)) + 1.0, 2.0), 4096.0))
+        best, R = 1e300, rmax
+        for rr in range(max(2, rmax - lmax), rmax + 1):
+            cost = (15.0 + (rr + lmax - 1) // lmax) / rr
+            if cost <= best:
+                best, R = cost, rr
+        nseg = (R + lmax - 1) // lmax
+        return R, (R + nseg - 1) // nseg
+
+    def _global_max_disp0(self):
+        d0 = C.c_double()
+        self._chk(self._L.md_dom_max_disp0(self._h, C.byref(d0)))
+        return self.ex.allreduce([d0.value], op="max")[0]
+
     def run_native(self, nsteps, dt, ensemble=_lib.MD_NVE, tau=0.0, nf=None, ktemp=None, r1=None, r2=None):
         """run_async() with the window loop inside the library (md_dom_run_window): one C call per window,
-        RCCL issued by the library on its own stream.  List builds (every ~25 steps) still go through
-        torch.distributed.  Returns global (U, W, K) of the last step."""
+        RCCL issued by the library on its own stream.  List builds still go through torch.distributed.
+        With enable_pruning() the windows span a whole rebuild interval with prune steps inside; the schedule
+        is planned from all-reduced displacement measurements, so every rank plans the same one.
+        Returns global (U, W, K) of the last step."""
         self._native_setup()
         nf = float(self.dim * (self.n_global - 1.0)) if nf is None else float(nf)
         nvt = ensemble == _lib.MD_NVT
@@ -506,26 +548,59 @@ class DomainDevice:
             r1 = np.ascontiguousarray(r1, dtype=np.float64)
             r2 = np.ascontiguousarray(r2, dtype=np.float64)
         uwk = (C.c_double * 3)()
+        info = (C.c_double * 6)()
         fv = C.c_int32()
         U = W = K = float("nan")
         L, h = self._L, self._h
         if self.builds == 0:
             self.build()
+        if not hasattr(self, "_rate"):
+            self._rate, self._rate_known, self._safety = 0.0, False, 0.97
+            self._pruning = bool(getattr(self, "_prune_req", False))
+            self._skins = (0.0, 0.0)
         s = 0
         while s < nsteps:
-            wlen = int(min(nsteps - s, max(1, self.target_interval - self.steps_since_build)))
+            R, Lp = None, 0
+            if self._pruning:
+                if not self._rate_known:
+                    R, Lp = self.steps_since_build + 4, 4     # a short first window, measured at its end
+                else:
+                    R, Lp = self._plan(*self._skins)
+                wlen = int(min(nsteps - s, max(1, R - self.steps_since_build)))
+            else:
+                wlen = int(min(nsteps - s, max(1, self.target_interval - self.steps_since_build)))
             arrs = [a[s:s + wlen].ctypes.data_as(dp) if nvt else None for a in (ktemp, r1, r2)]
             ends_run = s + wlen == nsteps
             self._chk(L.md_dom_run_window(h, wlen, float(dt), int(ensemble), float(tau), nf, *arrs,
-                                          1 if ends_run else 0, 1 if ends_run else 0, C.byref(fv), uwk))
+                                          1 if ends_run else 0, 1 if ends_run else 0, int(Lp), C.byref(fv), uwk, info))
+            pruning = info[3] > 0.0
+            self._skins = (info[4], info[5])
             if fv.value < wlen:
+                # step m's drift left the validity radius of the rows in use on some rank: every rank holds the
+                # drifted positions and skipped everything after; refresh the rows and redo step m's force half
                 m = int(fv.value)
                 g = s + m
                 last = g == nsteps - 1
                 self.violations += 1
-                observed = self.steps_since_build + m + 1
-                self.target_interval = max(2, (observed * 4) // 5)
-                self.build()
+                ssb = self.steps_since_build + m + 1
+                rebuild = True
+                if pruning:
+                    self._safety = max(0.5, self._safety - 0.02)
+                    d0 = self._global_max_disp0()
+                    sample = d0 / ssb
+                    if not self._rate_known:
+                        self._rate, self._rate_known = sample, True
+                    elif sample > self._rate:
+                        self._rate = 0.5 * (self._rate + sample)
+                    # a prune is enough while the outer rows still hold with room for a prune interval
+                    rebuild = info[0] > 0.0 or not (d0 + 0.5 * info[5] <= 0.5 * info[4])
+                else:
+                    self.target_interval = max(2, (ssb * 4) // 5)
+                if rebuild:
+                    self.build()
+                else:
+                    self._chk(L.md_dom_invalidate_inner(h))
+                    self.steps_since_build = ssb
                 self._chk(L.md_dom_forces(h, float(dt), 1, 1 if last else 0, uwk))
                 if nvt or last:
                     U, W, K = self.ex.allreduce([uwk[0], uwk[1], uwk[2]])
@@ -542,9 +617,21 @@ class DomainDevice:
                 s += wlen
                 if ends_run:
                     U, W, K = uwk[0], uwk[1], uwk[2]
-                elif self.steps_since_build >= self.target_interval:
+                if pruning:
+                    if not self._rate_known:
+                        self._rate = self._global_max_disp0() / max(1, self.steps_since_build)
+                        self._rate_known = True
+                    else:
+                        d1g, bl = self.ex.allreduce([info[1], info[2]], op="max")
+                        if bl > 0.0:
+                            self._rate = 0.7 * self._rate + 0.3 * (d1g / bl)
+                        self._safety = min(0.99, self._safety + 0.002)
+                        if not ends_run and R is not None and self.steps_since_build >= R:
+                            self.build()
+                elif not ends_run and self.steps_since_build >= self.target_interval:
                     self.build()
                     self.target_interval += 1
+            self._pruning = pruning
         return U, W, K
 
     def run(self, nsteps, dt, ensemble=_lib.MD_NVE, tau=0.0, nf=None, ktemp=None, r1=None, r2=None):

@@ -37,6 +37,8 @@ def main():
     ens = _lib.MD_NVT if nvt else _lib.MD_NVE
     with DomainDevice(3, n, s["box"], 2.5, ex, device_id=0) as d:
         d.set_potential(0, LJ)
+        if os.environ.get("DOM_PRUNE", "0") == "1":
+            d.enable_pruning()          # inner rows: prune steps scheduled inside the windows (run_native)
         d.upload_global(s["x"], s["v"], s["f"], s["img"], s["diam"])
         U, W = d.compute_forces()
         X0, V0, F0, I0 = d.gather_global()
@@ -45,7 +47,7 @@ def main():
         runner = {"0": d.run, "1": d.run_async, "native": d.run_native}[os.environ.get("DOM_ASYNC", "0")]
         Ue, We, Ke = runner(nsteps, 0.002, ens, 0.1, nf, kt, r1, r2)
         X, V, F, IM = d.gather_global()
-        stats = (d.builds, d.violations, d.counts())
+        stats = (d.builds, d.violations, d.counts(), d.stats()["prunes"])
     ok = True
     if rank == 0:
         from oracle import oracle as orc
@@ -62,10 +64,12 @@ def main():
             x1, v1, f1, im1 = g.download()
         dx, dv = np.abs(X - x1).max(), np.abs(V - v1).max()
         print(f"[dom] {nsteps} steps {'NVT' if nvt else 'NVE'}: dx={dx:.2e} dv={dv:.2e} dK={abs(Ke-K1)/K1:.2e} "
-              f"dU={abs(Ue-U1)/abs(U1):.2e} images_equal={np.array_equal(IM, im1)} builds={stats[0]} viol={stats[1]} {stats[2]}")
+              f"dU={abs(Ue-U1)/abs(U1):.2e} images_equal={np.array_equal(IM, im1)} builds={stats[0]} viol={stats[1]} {stats[2]} prunes={stats[3]}")
         ok &= dx <= 1e-8 and dv <= 1e-8 and abs(Ke - K1) <= 1e-9 * K1 and abs(Ue - U1) <= 1e-9 * abs(U1)
         ok &= np.array_equal(IM, im1)
         ok &= stats[0] >= 2          # at least one rebuild with migration happened
+        if os.environ.get("DOM_PRUNE", "0") == "1":
+            ok &= stats[3] >= 3      # and the inner rows were in use
     flag = [ok]
     dist.broadcast_object_list(flag, src=0)
     dist.destroy_process_group()

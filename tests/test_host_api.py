@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_loads_and_exports_every_declared_symbol():
     lib = _lib.load()
     header = open(os.path.join(ROOT, "include", "mdhip.h")).read()
-    declared = set(re.findall(r"\b(md_[a-z_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(md_[a-z0-9_]+)\s*\(", header))
     declared -= {"md_ctx"}
     assert declared == set(_lib.EXPORTS), f"header and binding disagree: {declared ^ set(_lib.EXPORTS)}"
     for name in declared:
