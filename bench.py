@@ -177,6 +177,20 @@ def main():
             dev.set_skin(a.skin)
         elif loop == "native" and os.environ.get("MDHIP_DOM_PRUNE", "1") == "1":
             dev.enable_pruning()           # skin 0.6 + inner rows 0.16, prune steps scheduled inside the windows
+        if loop == "native":
+            # bind RCCL inside the library now; if any rank cannot, every rank falls back to the torch.distributed-
+            # driven loop (same scheme, same planner)
+            ok = 1
+            try:
+                dev._native_setup()
+            except Exception as e:                                  # noqa: BLE001
+                ok = 0
+                print(f"[bench] rank {rank}: native RCCL transport unavailable ({e}); falling back", file=sys.stderr)
+            tok = torch.tensor([ok], dtype=torch.int32, device=ex.coll_device)
+            dist.all_reduce(tok, op=dist.ReduceOp.MIN)
+            if int(tok.item()) == 0:
+                loop = "async"
+                stepper = dev.run_async
         xg = inp["x"].copy()
         xg[:, 0] += rank * L1
         ids = (rank * a.n + np.arange(a.n)).astype(np.int32)

@@ -184,11 +184,12 @@ int md_dom_counts(md_ctx *ctx, int64_t *out /* [6]: n_own, nsend_halo L,R, nrecv
  * stream-ordered RCCL calls interleave with the kernels without host synchronisation.                    */
 int md_set_stream(md_ctx *ctx, void *hip_stream);
 int md_dom_async_begin(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, double tau, double nf, const double *ktemp,
-                       const double *r1, const double *r2, void *flag_dev /* int32[1] */, void *kuw_dev /* double[3] */);
+                       const double *r1, const double *r2, int64_t prune_interval, void *flag_dev /* int32[1] */,
+                       void *kuw_dev /* double[3] */);
 int md_dom_step_a(md_ctx *ctx, double dt, int step);
 int md_dom_step_b(md_ctx *ctx, double dt, int step, int want_uw);
 int md_dom_step_c(md_ctx *ctx, int step, int want_uw);
-int md_dom_async_end(md_ctx *ctx, int apply_pending_scale, int32_t *first_viol, double *uwk);
+int md_dom_async_end(md_ctx *ctx, int apply_pending_scale, int32_t *first_viol, double *uwk, double *info /* [6] or NULL */);
 
 /* Native transport: the same window of steps run entirely inside the library, which issues the three small
  * collectives of a step itself -- RCCL (over xGMI) on the handle's stream.  RCCL is bound at run time from
@@ -203,8 +204,8 @@ int md_dom_run_window(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, doub
                       const double *r1, const double *r2, int report_last, int apply_pending_scale,
                       int64_t prune_interval, int32_t *first_viol, double *uwk, double *info /* [6] or NULL */);
 /* Inner rows (see md_set_inner_skin) on a slab handle.  Every rank must prune at the same steps, so the caller
- * plans the schedule from all-reduced quantities: prune_interval = steps between prune steps inside a window
- * (0 = none scheduled); info returns {1 if the violating step was a prune step, this rank's d1 = max|x - x0| at
+ * plans the schedule from all-reduced quantities: prune_interval (md_dom_async_begin / md_dom_run_window) = steps
+ * between prune steps inside a window (0 = none scheduled); info (md_dom_async_end / md_dom_run_window) returns {1 if the violating step was a prune step, this rank's d1 = max|x - x0| at
  * the last executed prune step, steps since the build at that prune step or -1, 1 if pruning is active,
  * effective skin, effective inner skin}.
  * After a violation: all-reduce(MAX) md_dom_max_disp0; if the outer rows still hold (d0 + inner_skin/2 <=

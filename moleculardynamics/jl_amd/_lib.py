@@ -105,12 +105,12 @@ def load():
     L.md_dom_set_scale.argtypes = [vp, C.c_double]
     L.md_dom_counts.argtypes = [vp, i64p]
     L.md_set_stream.argtypes = [vp, C.c_void_p]
-    L.md_dom_async_begin.argtypes = [vp, C.c_int64, C.c_double, C.c_int, C.c_double, C.c_double, dp, dp, dp, C.c_void_p,
-                                     C.c_void_p]
+    L.md_dom_async_begin.argtypes = [vp, C.c_int64, C.c_double, C.c_int, C.c_double, C.c_double, dp, dp, dp, C.c_int64,
+                                     C.c_void_p, C.c_void_p]
     L.md_dom_step_a.argtypes = [vp, C.c_double, C.c_int]
     L.md_dom_step_b.argtypes = [vp, C.c_double, C.c_int, C.c_int]
     L.md_dom_step_c.argtypes = [vp, C.c_int, C.c_int]
-    L.md_dom_async_end.argtypes = [vp, C.c_int, C.POINTER(C.c_int32), dp]
+    L.md_dom_async_end.argtypes = [vp, C.c_int, C.POINTER(C.c_int32), dp, dp]
     L.md_dom_comm_unique_id.argtypes = [C.c_char_p, C.c_void_p]
     L.md_dom_comm_init.argtypes = [vp, C.c_char_p, C.c_void_p]
     L.md_dom_run_window.argtypes = [vp, C.c_int64, C.c_double, C.c_int, C.c_double, C.c_double, dp, dp, dp, C.c_int, C.c_int,

@@ -107,6 +107,8 @@ struct md_ctx {
         double *kuw_dev = nullptr;   // [3] K, U, W partial sums of this rank (SUM-reduced)
         bool a_nvt = false;
         double a_nf = 0.0, a_term1 = 0.0;
+        int64_t w_nsteps = 0, w_b0 = 0, w_prune_interval = 0; // the window being enqueued
+        std::vector<int> w_prune_steps;
         // native transport (md_dom_comm_init): RCCL called by the library on the handle's stream
         ncclComm_t comm = nullptr;
         bool prune_enabled = false; // inner rows on a slab handle: the caller plans the (globally identical) schedule
@@ -1871,7 +1873,8 @@ int md_set_stream(md_ctx *ctx, void *stream)
 }
 
 int md_dom_async_begin(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, double tau, double nf,
-                       const double *ktemp, const double *r1, const double *r2, void *flag_dev, void *kuw_dev)
+                       const double *ktemp, const double *r1, const double *r2, int64_t prune_interval, void *flag_dev,
+                       void *kuw_dev)
 {
     API_BEGIN
     dom_require(ctx);
@@ -1885,6 +1888,10 @@ int md_dom_async_begin(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, dou
     d.a_nvt = ensemble == MD_NVT;
     d.a_nf = nf;
     d.a_term1 = 0.0;
+    d.w_nsteps = nsteps;
+    d.w_b0 = ctx->steps_since_build;
+    d.w_prune_interval = prune_interval;
+    d.w_prune_steps.clear();
     if (d.a_nvt) {
         if (!ktemp || !r1 || !r2) throw HipError("md_dom_async_begin: NVT needs ktemp, r1, r2");
         if (!(tau > 0.0) || !(nf > 0.0)) throw HipError("md_dom_async_begin: NVT needs tau > 0 and nf > 0");
@@ -1909,6 +1916,10 @@ int md_dom_step_a(md_ctx *ctx, double dt, int step)
     API_BEGIN
     auto &d = ctx->dom;
     hipStream_t st = ctx->stream;
+    // inner rows: the schedule (identical on every rank) is the caller's prune interval
+    if (ctx->prune_on && ctx->inner_valid && d.w_prune_interval > 0 && ctx->steps_since_prune >= d.w_prune_interval)
+        ctx->inner_valid = false;
+    if (ctx->prune_on && !ctx->inner_valid) d.w_prune_steps.push_back(step);
     if (ctx->n > 0) launch_kickdrift(ctx, true, dt, true, step);
     DevState s = ctx->dev(ctx->cur);
     double shift_l = (d.rank == 0) ? ctx->L[0] : 0.0;
@@ -1941,6 +1952,7 @@ int md_dom_step_b(md_ctx *ctx, double dt, int step, int want_uw)
     k_dom_local_sums<<<1, 1024, 0, st>>>(ctx->n > 0 ? ctx->nblk : 0, ctx->partials.p, want_uw, d.kuw_dev, ctx->scal.p, step);
     HIPCHK(hipGetLastError());
     ctx->st_steps += 1;
+    ctx->steps_since_prune += 1;
     API_END
 }
 
@@ -1957,7 +1969,7 @@ int md_dom_step_c(md_ctx *ctx, int step, int want_uw)
 
 // waits for the window; first_viol = first step at which some rank's displacement check failed (or
 // 0x7fffffff); uwk = global {U, W, K} of the last executed step that reported them
-int md_dom_async_end(md_ctx *ctx, int apply_pending_scale, int32_t *first_viol, double *uwk)
+int md_dom_async_end(md_ctx *ctx, int apply_pending_scale, int32_t *first_viol, double *uwk, double *info)
 {
     API_BEGIN
     dom_require(ctx);
@@ -1978,6 +1990,28 @@ int md_dom_async_end(md_ctx *ctx, int apply_pending_scale, int32_t *first_viol, 
         uwk[0] = h.U;
         uwk[1] = h.W;
         uwk[2] = h.K;
+    }
+    // bookkeeping + what the caller's planner needs
+    auto &d = ctx->dom;
+    int64_t fv = h.first_viol;
+    int64_t done = fv < d.w_nsteps ? fv + 1 : d.w_nsteps; // steps whose drift was executed
+    ctx->steps_since_build = d.w_b0 + done;
+    bool was_prune = false;
+    int last_prune = -1;
+    for (int p : d.w_prune_steps) {
+        if (p == fv) was_prune = true;
+        if (p < fv && p < d.w_nsteps) last_prune = p;
+    }
+    if (info) {
+        double d12;
+        unsigned long long bits = h.d1max2_bits;
+        memcpy(&d12, &bits, sizeof d12);
+        info[0] = was_prune ? 1.0 : 0.0;
+        info[1] = std::sqrt(d12);
+        info[2] = last_prune >= 0 ? (double)(d.w_b0 + last_prune + 1) : -1.0;
+        info[3] = ctx->prune_on ? 1.0 : 0.0;
+        info[4] = ctx->skin;
+        info[5] = ctx->prune_on ? ctx->inner_skin : 0.0;
     }
     API_END
 }
@@ -2084,19 +2118,14 @@ int md_dom_run_window(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, doub
     dom_require(ctx);
     auto &d = ctx->dom;
     if (!d.comm) throw HipError("md_dom_run_window: no communicator (md_dom_comm_init first)");
-    int rc = md_dom_async_begin(ctx, nsteps, dt, ensemble, tau, nf, ktemp, r1, r2, d.own_flag.p, d.own_kuw.p);
+    int rc = md_dom_async_begin(ctx, nsteps, dt, ensemble, tau, nf, ktemp, r1, r2, prune_interval, d.own_flag.p,
+                                d.own_kuw.p);
     if (rc != 0) return rc;
     hipStream_t st = ctx->stream;
     const int left = (d.rank + d.nranks - 1) % d.nranks, right = (d.rank + 1) % d.nranks;
     const bool nvt = d.a_nvt;
-    const int64_t b0 = ctx->steps_since_build;
-    std::vector<int> prune_steps;
     for (int64_t t = 0; t < nsteps; ++t) {
         int want = (report_last && t == nsteps - 1) ? 1 : 0;
-        // inner rows: the schedule (identical on every rank) comes from the caller
-        if (ctx->prune_on && ctx->inner_valid && prune_interval > 0 && ctx->steps_since_prune >= prune_interval)
-            ctx->inner_valid = false;
-        if (ctx->prune_on && !ctx->inner_valid) prune_steps.push_back((int)t);
         rc = md_dom_step_a(ctx, dt, (int)t);
         if (rc != 0) return rc;
         g_rccl.check(g_rccl.AllReduce(d.flag_dev, d.flag_dev, 1, ncclInt32, ncclMin, d.comm, st), "ncclAllReduce(flag)");
@@ -2121,34 +2150,8 @@ int md_dom_run_window(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, doub
             rc = md_dom_step_c(ctx, (int)t, want);
             if (rc != 0) return rc;
         }
-        ctx->steps_since_prune += 1;
     }
-    int32_t fv = MD_NO_VIOLATION;
-    rc = md_dom_async_end(ctx, apply_pending_scale, &fv, uwk);
-    if (rc != 0) return rc;
-    if (first_viol) *first_viol = fv;
-    // bookkeeping + what the caller's planner needs: info = {violating step was a prune step, this rank's d1 =
-    // max |x - x0| at the last executed prune step, steps since the build at that prune step (-1: none)}
-    int64_t done = fv < nsteps ? (int64_t)fv + 1 : nsteps; // steps whose drift was executed
-    ctx->steps_since_build = b0 + done;
-    bool was_prune = false;
-    int last_prune = -1;
-    for (int p : prune_steps) {
-        if (p == fv) was_prune = true;
-        if (p < fv && p < nsteps) last_prune = p;
-    }
-    if (info) {
-        Scalars h = read_scalars(ctx);
-        double d12;
-        unsigned long long bits = h.d1max2_bits;
-        memcpy(&d12, &bits, sizeof d12);
-        info[0] = was_prune ? 1.0 : 0.0;
-        info[1] = std::sqrt(d12);
-        info[2] = last_prune >= 0 ? (double)(b0 + last_prune + 1) : -1.0;
-        info[3] = ctx->prune_on ? 1.0 : 0.0;
-        info[4] = ctx->skin;
-        info[5] = ctx->prune_on ? ctx->inner_skin : 0.0;
-    }
+    return md_dom_async_end(ctx, apply_pending_scale, first_viol, uwk, info);
     API_END
 }
 

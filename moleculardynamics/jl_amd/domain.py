@@ -414,75 +414,33 @@ class DomainDevice:
         neighbour exchange of the halo coordinates and the all-reduce (SUM) of K/U/W alternate in stream order.
         A violation on any rank at step m reaches every rank through the reduced flag before step m's force
         evaluation, so all later kernels of the window skip themselves everywhere; the host reads the flag
-        once per window, rebuilds at the drifted positions and resumes -- the single-GPU scheme, globally.
+        once per window, refreshes the rows at the drifted positions and resumes -- the single-GPU scheme,
+        globally.  Collectives go through torch.distributed (RCCL: stream-ordered; gloo: staged, for tests).
         Returns global (U, W, K) of the last step."""
         self._async_setup()
         torch = self.ex.torch
-        nf = float(self.dim * (self.n_global - 1.0)) if nf is None else float(nf)
-        nvt = ensemble == _lib.MD_NVT
-        dp = C.POINTER(C.c_double)
-        if nvt:
-            ktemp = np.ascontiguousarray(ktemp, dtype=np.float64)
-            r1 = np.ascontiguousarray(r1, dtype=np.float64)
-            r2 = np.ascontiguousarray(r2, dtype=np.float64)
-        uwk = (C.c_double * 3)()
-        fv = C.c_int32()
-        U = W = K = float("nan")
         L, h = self._L, self._h
+
+        def window(wlen, dt, ensemble, tau, nf, arrs, nvt, ends_run, prune_interval, fv, uwk, info):
+            self._chk(L.md_dom_async_begin(h, wlen, float(dt), int(ensemble), float(tau), nf, *arrs, int(prune_interval),
+                                           C.c_void_p(self._flag.data_ptr()), C.c_void_p(self._kuw.data_ptr())))
+            sl, sr, rl, rr = self._zbufs
+            ns, nr = self._nsend_halo, self._nrecv_halo
+            sl, sr = sl[: ns[0] * POS_REC], sr[: ns[1] * POS_REC]
+            rl, rr = rl[: nr[0] * POS_REC], rr[: nr[1] * POS_REC]
+            for t in range(wlen):
+                last = ends_run and t == wlen - 1
+                self._chk(L.md_dom_step_a(h, float(dt), t))
+                self.ex.allreduce_dev(self._flag, "min")
+                self.ex.sendrecv_dev(sl, sr, rl, rr)
+                self._chk(L.md_dom_step_b(h, float(dt), t, 1 if last else 0))
+                if nvt or last:
+                    self.ex.allreduce_dev(self._kuw, "sum")
+                    self._chk(L.md_dom_step_c(h, t, 1 if last else 0))
+            self._chk(L.md_dom_async_end(h, 1 if ends_run else 0, C.byref(fv), uwk, info))
+
         with torch.cuda.stream(self._stream):
-            if self.builds == 0:
-                self.build()
-            s = 0
-            while s < nsteps:
-                wlen = int(min(nsteps - s, max(1, self.target_interval - self.steps_since_build)))
-                arrs = [a[s:s + wlen].ctypes.data_as(dp) if nvt else None for a in (ktemp, r1, r2)]
-                self._chk(L.md_dom_async_begin(h, wlen, float(dt), int(ensemble), float(tau), nf, *arrs,
-                                               C.c_void_p(self._flag.data_ptr()), C.c_void_p(self._kuw.data_ptr())))
-                sl, sr, rl, rr = self._zbufs
-                ns, nr = self._nsend_halo, self._nrecv_halo
-                sl, sr = sl[: ns[0] * POS_REC], sr[: ns[1] * POS_REC]
-                rl, rr = rl[: nr[0] * POS_REC], rr[: nr[1] * POS_REC]
-                ends_run = s + wlen == nsteps
-                for t in range(wlen):
-                    last = ends_run and t == wlen - 1
-                    self._chk(L.md_dom_step_a(h, float(dt), t))
-                    self.ex.allreduce_dev(self._flag, "min")
-                    self.ex.sendrecv_dev(sl, sr, rl, rr)
-                    self._chk(L.md_dom_step_b(h, float(dt), t, 1 if last else 0))
-                    if nvt or last:
-                        self.ex.allreduce_dev(self._kuw, "sum")
-                        self._chk(L.md_dom_step_c(h, t, 1 if last else 0))
-                self._chk(L.md_dom_async_end(h, 1 if ends_run else 0, C.byref(fv), uwk))
-                if fv.value < wlen:
-                    # step m's drift left the rows' validity radius on some rank: every rank holds the drifted
-                    # positions and skipped everything after; rebuild there and redo the force half of step m
-                    m = int(fv.value)
-                    g = s + m
-                    last = g == nsteps - 1
-                    self.violations += 1
-                    observed = self.steps_since_build + m + 1
-                    self.target_interval = max(2, (observed * 4) // 5)
-                    self.build()
-                    self._chk(L.md_dom_forces(h, float(dt), 1, 1 if last else 0, uwk))
-                    if nvt or last:
-                        U, W, K = self.ex.allreduce([uwk[0], uwk[1], uwk[2]])
-                    if nvt:
-                        scale = float(bussi_scale(K, ktemp[g], nf, dt, tau, r1[g], r2[g]))
-                        K = K * scale * scale
-                        if last:
-                            self._chk(L.md_scale_velocities(h, scale))
-                        else:
-                            self._chk(L.md_dom_set_scale(h, scale))
-                    s = g + 1
-                else:
-                    self.steps_since_build += wlen
-                    s += wlen
-                    if ends_run:
-                        U, W, K = uwk[0], uwk[1], uwk[2]
-                    elif self.steps_since_build >= self.target_interval:
-                        self.build()
-                        self.target_interval += 1
-        return U, W, K
+            return self._run_planned(window, nsteps, dt, ensemble, tau, nf, ktemp, r1, r2)
 
     # -- native transport: the window loop inside the library, RCCL issued by the library ----------------
     def _native_setup(self):
@@ -536,10 +494,23 @@ class DomainDevice:
     def run_native(self, nsteps, dt, ensemble=_lib.MD_NVE, tau=0.0, nf=None, ktemp=None, r1=None, r2=None):
         """run_async() with the window loop inside the library (md_dom_run_window): one C call per window,
         RCCL issued by the library on its own stream.  List builds still go through torch.distributed.
-        With enable_pruning() the windows span a whole rebuild interval with prune steps inside; the schedule
-        is planned from all-reduced displacement measurements, so every rank plans the same one.
         Returns global (U, W, K) of the last step."""
         self._native_setup()
+        L, h = self._L, self._h
+
+        def window(wlen, dt, ensemble, tau, nf, arrs, nvt, ends_run, prune_interval, fv, uwk, info):
+            self._chk(L.md_dom_run_window(h, wlen, float(dt), int(ensemble), float(tau), nf, *arrs,
+                                          1 if ends_run else 0, 1 if ends_run else 0, int(prune_interval), C.byref(fv),
+                                          uwk, info))
+
+        return self._run_planned(window, nsteps, dt, ensemble, tau, nf, ktemp, r1, r2)
+
+    def _run_planned(self, window, nsteps, dt, ensemble, tau, nf, ktemp, r1, r2):
+        """The window planner shared by run_async and run_native.  Without inner rows a window runs up to the
+        next scheduled list build.  With enable_pruning() it spans a whole rebuild interval with prune steps
+        inside; rebuild and prune intervals are planned from all-reduced displacement measurements, so every
+        rank plans the same schedule (the prune steps must coincide: a rank's rows contain its neighbours'
+        particles, whose displacement is checked by their owner against the owner's own prune positions)."""
         nf = float(self.dim * (self.n_global - 1.0)) if nf is None else float(nf)
         nvt = ensemble == _lib.MD_NVT
         dp = C.POINTER(C.c_double)
@@ -571,8 +542,7 @@ class DomainDevice:
                 wlen = int(min(nsteps - s, max(1, self.target_interval - self.steps_since_build)))
             arrs = [a[s:s + wlen].ctypes.data_as(dp) if nvt else None for a in (ktemp, r1, r2)]
             ends_run = s + wlen == nsteps
-            self._chk(L.md_dom_run_window(h, wlen, float(dt), int(ensemble), float(tau), nf, *arrs,
-                                          1 if ends_run else 0, 1 if ends_run else 0, int(Lp), C.byref(fv), uwk, info))
+            window(wlen, dt, ensemble, tau, nf, arrs, nvt, ends_run, Lp, fv, uwk, info)
             pruning = info[3] > 0.0
             self._skins = (info[4], info[5])
             if fv.value < wlen:

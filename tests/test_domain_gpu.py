@@ -27,6 +27,8 @@ def _launch(nproc, env_extra, port):
     (2, 0, "", "sync"), (3, 0, "", "sync"), (2, 1, "", "sync"), (2, 0, "device", "sync"),
     # the asynchronous step loop (no host wait per step; flags and K/U/W all-reduced on the device)
     (2, 0, "device", "async"), (2, 1, "device", "async"), (3, 1, "device", "async"),
+    # ... with inner rows: every rank must plan the same prune schedule from all-reduced measurements
+    (2, 0, "device", "async-prune"), (2, 1, "device", "async-prune"), (3, 1, "device", "async-prune"),
     # the real RCCL transport, one rank whose left and right neighbours are itself: stream-ordered
     # collectives and self send/recv between the library's kernels
     (1, 1, "", "nccl-sync"), (1, 0, "", "nccl-async"), (1, 1, "", "nccl-async"),
@@ -40,9 +42,9 @@ def test_slab_decomposition_matches_single_gpu(nproc, nvt, stage, mode):
     # particles migrate between slabs and cross the periodic faces within the run
     # stage == "device": exchange buffers live on the GPU (the RCCL-path plumbing) although gloo carries them
     env = {"DOM_N": "8000", "DOM_KT": "2.0", "DOM_STEPS": "60", "DOM_NVT": str(nvt), "MDHIP_DOM_STAGE": stage,
-           "DOM_ASYNC": "native" if "native" in mode else ("1" if mode.endswith("async") else "0"),
+           "DOM_ASYNC": "native" if "native" in mode else ("1" if "async" in mode else "0"),
            "DOM_PRUNE": "1" if mode.endswith("prune") else "0", "DOM_STEPS": "120" if mode.endswith("prune") else "60",
            "DOM_BACKEND": "nccl" if mode.startswith("nccl") else "gloo"}
     port = 29511 + nproc + 10 * nvt + (20 if stage else 0) + {"sync": 0, "async": 40, "nccl-sync": 80, "nccl-async": 120,
-                                                                "nccl-native": 160, "nccl-native-prune": 200}[mode]
+                                                                "nccl-native": 160, "nccl-native-prune": 200, "async-prune": 240}[mode]
     _launch(nproc, env, port)
