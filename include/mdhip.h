@@ -104,6 +104,17 @@ int md_neighbor_pairs(md_ctx *ctx, int32_t *pairs, int64_t cap, int64_t *count);
 int md_run(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, double tau, double nf, const double *ktemp,
            const double *r1, const double *r2, double *uwk);
 
+/* fire_minimize!: src/minimize.jl:31-135 -- FIRE relaxation on the same force path, device resident (the whole
+ * scalar state -- dt, alpha, counters, convergence -- lives on the device; the host only waits every 32 steps).
+ * Positions, images and forces of the handle are updated; its velocities are left as they were (FIRE's own
+ * velocities are internal and start at zero, :57).  Keyword defaults of the reference: max_steps 10000,
+ * tol 1e-6, dt_initial 0.01, dt_max 0.1, alpha0 0.1, f_inc 1.2, f_dec 0.2, Nmin 5.  *steps = force evaluations
+ * consumed by the loop (the converging one included); *energy, *f_rms = F_norm/sqrt(d(N-1)) of the last force
+ * evaluation (after max_steps without convergence that is the closing evaluation of :126-129).            */
+int md_fire_minimize(md_ctx *ctx, int64_t max_steps, double tol, double dt_initial, double dt_max, double alpha0,
+                     double f_inc, double f_dec, int nmin, int64_t *steps, int *converged, double *energy,
+                     double *f_rms);
+
 /* compute_kinetic: src/thermostat.jl:50-60 */
 int md_kinetic(md_ctx *ctx, double *kinetic);
 

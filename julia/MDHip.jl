@@ -12,7 +12,7 @@ using Random, Printf, LinearAlgebra, Statistics
 using Distributions: Gamma
 
 export Parameters, NVT, NVE, Potential, evaluate, LennardJones, PseudoHS, Polydisperse,
-       initialize_state, initialize_velocities, run_simulation!, LinearRamp, ExponentialRamp
+       initialize_state, initialize_velocities, run_simulation!, LinearRamp, ExponentialRamp, fire_minimize!
 
 const LIB = get(ENV, "MDHIP_LIB", joinpath(@__DIR__, "..", "moleculardynamics", "jl_amd", "csrc", "libmdhip.so"))
 
@@ -217,6 +217,30 @@ function run_simulation!(state::SimulationState, params::Parameters, ensemble::E
                      dev.h, X, V, F, state.images))
     unpack!(state.system.positions, X); unpack!(state.system.energy_and_forces.forces, F)
     state.velocities = [V[:, i] for i in 1:n]
+    return nothing
+end
+
+# ---- fire_minimize!: src/minimize.jl:31-135 (same keywords and defaults; returns (energy, true) or nothing) ----
+function fire_minimize!(state::SimulationState, params::Parameters; dimension::Int=2, max_steps::Int=10000,
+                        tol::Float64=1e-6, dt_initial::Float64=0.01, dt_max::Float64=0.1, alpha0::Float64=0.1,
+                        f_inc::Float64=1.2, f_dec::Float64=0.2, Nmin::Int=5)
+    dev = state.system.device; d = state.dimension; n = params.n_particles
+    kind, pp = device_spec(params.potential)
+    check(dev, ccall((:md_set_potential, LIB), Cint, (Ptr{Cvoid}, Cint, Ptr{Float64}, Cint), dev.h, kind, pp, length(pp)))
+    X = pack(state.system.positions, d); F = pack(state.system.energy_and_forces.forces, d)
+    check(dev, ccall((:md_upload, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}, Ptr{Float64}),
+                     dev.h, X, C_NULL, F, state.images, state.diameters))
+    steps = Ref{Int64}(0); conv = Ref{Cint}(0); energy = Ref{Float64}(0.0); frms = Ref{Float64}(0.0)
+    rc = @ccall gc_safe=true LIB.md_fire_minimize(dev.h::Ptr{Cvoid}, max_steps::Int64, tol::Float64, dt_initial::Float64,
+                      dt_max::Float64, alpha0::Float64, f_inc::Float64, f_dec::Float64, Nmin::Cint, steps::Ptr{Int64},
+                      conv::Ptr{Cint}, energy::Ptr{Float64}, frms::Ptr{Float64})::Cint
+    check(dev, rc)
+    check(dev, ccall((:md_download, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Int32}),
+                     dev.h, X, C_NULL, F, state.images))
+    unpack!(state.system.positions, X); unpack!(state.system.energy_and_forces.forces, F)
+    state.system.energy_and_forces.energy = energy[]
+    conv[] != 0 && return energy[], true
+    @warn "FIRE did not converge after $(max_steps) steps; final F_norm = $(frms[])"
     return nothing
 end
 

@@ -7,6 +7,7 @@ from .temperature_ramps import LinearRamp, ExponentialRamp, initial_temperature_
 from .initialization import (initialize_state, initialize_velocities, lattice_positions, to_unitcell,
                              SimulationState, EnergyAndForces)
 from .simulation import run_simulation
+from .minimize import fire_minimize, minimize
 from .device import MDDevice
 from ._lib import MdhipError
 
@@ -14,4 +15,5 @@ __all__ = [
     "Parameters", "NVT", "NVE", "Brownian", "initialize_state", "run_simulation", "PseudoHS", "LennardJones",
     "Polydisperse", "LinearRamp", "ExponentialRamp", "initial_temperature_for_velocities",
     "initialize_velocities", "Potential", "evaluate", "MDDevice", "MdhipError", "lattice_positions",
+    "fire_minimize", "minimize",
 ]

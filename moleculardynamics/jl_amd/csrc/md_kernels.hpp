@@ -1113,6 +1113,136 @@ __global__ void __launch_bounds__(1024)
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// FIRE relaxation (src/minimize.jl:31-135) on the same force kernel.  Per step: forces (k_force_tile,
+// KICK = false, U/W partials) -> k_fire_a (v += dt f; partial sums of |f|^2, v.f, |v|^2) -> k_fire_reduce
+// (one block: convergence test, mixing coefficients, dt / alpha / counter update -- the whole scalar state
+// lives on the device) -> k_fire_b (mix or zero v, x += dt_new v, displacement check of the rows).
+// FIRE's velocities occupy the state's velocity arrays for the duration (md_fire_minimize saves and
+// restores the MD velocities), so a list rebuild permutes them with everything else.
+// ------------------------------------------------------------------------------------------
+struct FireState {
+    double dt, alpha;                              // evolving
+    double dt_initial, dt_max, alpha0, f_inc, f_dec, tol, ndof;
+    int since_neg, nmin;
+    int converged, conv_step;                      // step (0-based) whose forces met the tolerance
+    double energy, f_rms;                          // of the last executed force evaluation
+    double mix_keep, mix_scale;                    // v <- mix_keep * v + mix_scale * f   (this step)
+    int zero_v;                                    // P <= 0: v <- 0
+    int steps;                                     // force evaluations consumed by the loop
+};
+
+template <int D>
+__global__ void __launch_bounds__(MD_BLOCK)
+    k_fire_a(int n, DevState s, const FireState *fs, double *__restrict__ part, int nblk, const Scalars *sc, int step)
+{
+    __shared__ double red[16];
+    if (sc->first_viol <= step) return;
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    double dt = fs->dt;
+    double f2 = 0.0, vf = 0.0, v2 = 0.0;
+    if (k < n) {
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            double fc = s.f[c][k];
+            double vc = s.v[c][k] + dt * fc; // src/minimize.jl:89-91
+            s.v[c][k] = vc;
+            f2 += fc * fc;
+            vf += vc * fc;
+            v2 += vc * vc;
+        }
+    }
+    f2 = block_sum(f2, red);
+    vf = block_sum(vf, red);
+    v2 = block_sum(v2, red);
+    if (threadIdx.x == 0) {
+        part[blockIdx.x] = f2;
+        part[nblk + blockIdx.x] = vf;
+        part[2 * nblk + blockIdx.x] = v2;
+    }
+}
+
+__global__ void __launch_bounds__(1024)
+    k_fire_reduce(int nblk, const double *__restrict__ part, int nblk_force, const double *__restrict__ force_part,
+                  FireState *fs, Scalars *sc, int step)
+{
+    __shared__ double red[16];
+    if (sc->first_viol <= step) return;
+    double f2 = 0.0, vf = 0.0, v2 = 0.0, u = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += blockDim.x) {
+        f2 += part[i];
+        vf += part[nblk + i];
+        v2 += part[2 * nblk + i];
+    }
+    for (int i = threadIdx.x; i < nblk_force; i += blockDim.x) u += force_part[nblk_force + i];
+    f2 = block_sum(f2, red);
+    vf = block_sum(vf, red);
+    v2 = block_sum(v2, red);
+    u = block_sum(u, red);
+    if (threadIdx.x != 0) return;
+    double fn = sqrt(f2), vn = sqrt(v2);
+    fs->energy = u / 2.0; // every pair was evaluated from both ends
+    fs->f_rms = fn / sqrt(fs->ndof);
+    fs->steps = step + 1;
+    sc->U = fs->energy;
+    if (fs->f_rms < fs->tol) { // src/minimize.jl:84-87: converged, positions stay as they are
+        fs->converged = 1;
+        fs->conv_step = step;
+        if (step < sc->first_viol) sc->first_viol = step; // everything enqueued after this kernel skips itself
+        return;
+    }
+    double alpha = fs->alpha;
+    if (vn > 0.0 && fn > 0.0) { // :95-102, with this step's alpha
+        fs->mix_keep = 1.0 - alpha;
+        fs->mix_scale = alpha * (vn / fn);
+    } else {
+        fs->mix_keep = 1.0;
+        fs->mix_scale = 0.0;
+    }
+    if (vf > 0.0) { // :104-109
+        fs->since_neg += 1;
+        if (fs->since_neg > fs->nmin) {
+            fs->dt = fmin(fs->dt * fs->f_inc, fs->dt_max);
+            fs->alpha = alpha * 0.99;
+        }
+        fs->zero_v = 0;
+    } else { // :110-115
+        fs->dt = fmax(fs->dt * fs->f_dec, fs->dt_initial);
+        fs->alpha = fs->alpha0;
+        fs->since_neg = 0;
+        fs->zero_v = 1;
+    }
+}
+
+template <int D>
+__global__ void __launch_bounds__(MD_BLOCK)
+    k_fire_b(int n, DevState s, const FireState *fs, double skin_half, Scalars *sc, int step)
+{
+    if (sc->first_viol <= step) return;
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    double keep = fs->mix_keep, scale = fs->mix_scale, dt = fs->dt;
+    bool zero = fs->zero_v != 0;
+    double disp2 = 0.0;
+    if (k < n) {
+        double4 p = s.pos[k];
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            double vc = keep * s.v[c][k] + scale * s.f[c][k];
+            if (zero) vc = 0.0;
+            s.v[c][k] = vc;
+            double xc = pos_get(p, c) + dt * vc; // :117-123 with the updated dt; the wrap is applied lazily
+            pos_set(p, c, xc);
+            double d = xc - s.x0[c][k];
+            disp2 = __builtin_fma(d, d, disp2);
+        }
+        s.pos[k] = p;
+    }
+    // the rows were built at x0 with margin 2*skin_half: the NEXT force evaluation needs a rebuild first
+    if (__any(disp2 > skin_half * skin_half)) {
+        if ((threadIdx.x & 63) == 0) atomicMin(&sc->first_viol, step + 1);
+    }
+}
+
 __global__ void k_set_scale(Scalars *sc, double v) { sc->scale = v; }
 __global__ void k_set_scale_unless_violated(Scalars *sc, double v)
 {

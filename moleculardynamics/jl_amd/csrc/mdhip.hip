@@ -157,6 +157,8 @@ struct md_ctx {
     int64_t ntiles = 0;
 
     DBuf<double> partials;
+    DBuf<double> fire_part;      // FIRE: per-block sums of |f|^2, v.f, |v|^2
+    DBuf<FireState> fire_state;
     int nblk = 0;
     DBuf<Scalars> scal;
     DBuf<double> d_kt, d_r1, d_r2;
@@ -1400,6 +1402,102 @@ int md_run(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, double tau, dou
         uwk[2] = h.K;
     }
     ctx->st_steps += nsteps;
+    API_END
+}
+
+// fire_minimize!: src/minimize.jl:31-135 (kernels and scheme: md_kernels.hpp, "FIRE relaxation")
+int md_fire_minimize(md_ctx *ctx, int64_t max_steps, double tol, double dt_initial, double dt_max, double alpha0,
+                     double f_inc, double f_dec, int nmin, int64_t *steps, int *converged, double *energy,
+                     double *f_rms)
+{
+    API_BEGIN
+    if (ctx->dom.on) throw HipError("md_fire_minimize: not available on a slab-decomposition handle");
+    if (max_steps < 0 || max_steps > 0x3ffffff0) throw HipError("md_fire_minimize: bad max_steps");
+    if (!(dt_initial > 0.0) || !(dt_max >= dt_initial)) throw HipError("md_fire_minimize: need 0 < dt_initial <= dt_max");
+    hipStream_t st = ctx->stream;
+    const size_t nd = (size_t)ctx->n * ctx->dim;
+    // FIRE's velocities are internal and start at zero (src/minimize.jl:57): park the MD velocities on the host
+    std::vector<double> vsave(nd), zeros(nd, 0.0);
+    if (md_download(ctx, nullptr, vsave.data(), nullptr, nullptr) != 0) return 1;
+    if (md_upload(ctx, nullptr, zeros.data(), nullptr, nullptr, nullptr) != 0) return 1;
+    ctx->list_valid = false;
+    FireState hf{};
+    hf.dt = dt_initial;
+    hf.alpha = alpha0;
+    hf.dt_initial = dt_initial;
+    hf.dt_max = dt_max;
+    hf.alpha0 = alpha0;
+    hf.f_inc = f_inc;
+    hf.f_dec = f_dec;
+    hf.tol = tol;
+    hf.ndof = ctx->dim * ((double)ctx->n_global - 1.0);
+    hf.nmin = nmin;
+    hf.conv_step = -1;
+    hf.mix_keep = 1.0;
+    ctx->fire_state.ensure(1);
+    HIPCHK(hipMemcpyAsync(ctx->fire_state.p, &hf, sizeof hf, hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    auto eval = [&](int t, bool drift) {
+        // (rows: the outer ones -- KICK = false never prunes, and the rebuild below left no inner rows)
+        launch_force(ctx, true, false, 0.0, t);
+        DevState s = ctx->dev(ctx->cur);
+        int nb = ctx->nblk, n = (int)ctx->n;
+        ctx->fire_part.ensure((size_t)3 * nb);
+        if (ctx->dim == 3)
+            k_fire_a<3><<<nb, MD_BLOCK, 0, st>>>(n, s, ctx->fire_state.p, ctx->fire_part.p, nb, ctx->scal.p, t);
+        else
+            k_fire_a<2><<<nb, MD_BLOCK, 0, st>>>(n, s, ctx->fire_state.p, ctx->fire_part.p, nb, ctx->scal.p, t);
+        k_fire_reduce<<<1, 1024, 0, st>>>(nb, ctx->fire_part.p, nb, ctx->partials.p, ctx->fire_state.p, ctx->scal.p, t);
+        if (!drift) return;
+        if (ctx->dim == 3)
+            k_fire_b<3><<<nb, MD_BLOCK, 0, st>>>(n, s, ctx->fire_state.p, 0.5 * ctx->skin, ctx->scal.p, t);
+        else
+            k_fire_b<2><<<nb, MD_BLOCK, 0, st>>>(n, s, ctx->fire_state.p, 0.5 * ctx->skin, ctx->scal.p, t);
+    };
+    auto read_fire = [&]() {
+        HIPCHK(hipMemcpyAsync(&hf, ctx->fire_state.p, sizeof hf, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+    };
+    int64_t s = 0;
+    bool conv = false;
+    while (s < max_steps && !conv) {
+        if (!ctx->list_valid) rebuild(ctx); // (wraps the positions, resets the violation word)
+        int64_t chunk_end = std::min<int64_t>(max_steps, s + 32);
+        for (int64_t t = s; t < chunk_end; ++t) eval((int)t, true);
+        HIPCHK(hipGetLastError());
+        Scalars h = read_scalars(ctx);
+        read_fire();
+        if (hf.converged) {
+            conv = true;
+            s = (int64_t)hf.conv_step + 1;
+            k_reset_viol<<<1, 1, 0, st>>>(ctx->scal.p);
+            break;
+        }
+        if (h.first_viol <= chunk_end) {
+            // the drift of step first_viol-1 moved some particle skin/2 from its build position: the rows
+            // must be rebuilt before that step's successor evaluates forces (kernels after it skipped)
+            s = h.first_viol;
+            ctx->list_valid = false;
+            ctx->st_viol++;
+        } else {
+            s = chunk_end;
+        }
+    }
+    if (!conv) {
+        // src/minimize.jl:126-129: the closing force evaluation of a run that did not converge
+        if (!ctx->list_valid) rebuild(ctx);
+        double tol_keep = hf.tol;
+        eval(-1, false);
+        read_fire();
+        (void)tol_keep;
+        hf.converged = 0; // (the closing evaluation is not a convergence test)
+        k_reset_viol<<<1, 1, 0, st>>>(ctx->scal.p);
+    }
+    if (md_upload(ctx, nullptr, vsave.data(), nullptr, nullptr, nullptr) != 0) return 1;
+    if (steps) *steps = s;
+    if (converged) *converged = conv ? 1 : 0;
+    if (energy) *energy = hf.energy;
+    if (f_rms) *f_rms = hf.f_rms;
     API_END
 }
 

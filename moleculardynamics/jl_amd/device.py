@@ -131,6 +131,16 @@ class MDDevice:
                                  _dp(a2), _dp(uwk) if thermo else None))
         return (uwk[0], uwk[1], uwk[2]) if thermo else None
 
+    def fire_minimize(self, max_steps=10000, tol=1e-6, dt_initial=0.01, dt_max=0.1, alpha0=0.1, f_inc=1.2, f_dec=0.2,
+                      nmin=5):
+        """fire_minimize! (src/minimize.jl:31-135) on the device state; returns dict(steps, converged, energy, f_rms)."""
+        st, cv = C.c_int64(), C.c_int()
+        en, fr = C.c_double(), C.c_double()
+        self._chk(self._L.md_fire_minimize(self._h, int(max_steps), float(tol), float(dt_initial), float(dt_max),
+                                           float(alpha0), float(f_inc), float(f_dec), int(nmin), C.byref(st), C.byref(cv),
+                                           C.byref(en), C.byref(fr)))
+        return dict(steps=st.value, converged=bool(cv.value), energy=en.value, f_rms=fr.value)
+
     def kinetic(self):
         k = C.c_double()
         self._chk(self._L.md_kinetic(self._h, C.byref(k)))

@@ -564,6 +564,90 @@ int oracle_run(int dim, int n, double *x, int32_t *img, double *v, double *f, co
     return nout;
 }
 
+/* src/minimize.jl:31-135 fire_minimize! -- FIRE relaxation on the same pair map.  Per step (1-based):
+ *   forces + energy at x (:71-74); F_norm = sqrt(sum |f_i|^2) (:76); converged iff F_norm/sqrt(ndof) < tol,
+ *   returning the energy WITHOUT touching x (:84-87); v += dt*f (:89-91); P = sum v_i.f_i (:93);
+ *   if |v| > 0 and |f| > 0: v = (1-alpha) v + alpha (|v|/|f|) f (:95-102) -- mixed BEFORE the sign test, with
+ *   the alpha of this step; P > 0: ++steps_since_neg, and past Nmin dt = min(dt*f_inc, dt_max), alpha *= 0.99
+ *   (:104-109); else dt = max(dt*f_dec, dt_initial), v = 0, alpha = alpha0, counter = 0 (:110-115);
+ *   x += dt*v with the NEW dt, wrap + images (:117-123).
+ * v is internal (starts at zero, :57); ndof = dimension*(N-1) (:61).  Not converged after max_steps: forces
+ * are evaluated once more (:126-129) and the reference returns nothing.
+ * Returns the number of steps whose force evaluation ran (the converging step included); *converged,
+ * *energy (of the last force evaluation), *f_rms = F_norm/sqrt(ndof) of the last evaluation. */
+int oracle_fire_minimize(int dim, int n, double *x, int32_t *img, double *f, const double *diam, const double *L,
+                         double cutoff, const oracle_pot *pot, int max_steps, double tol, double dt_initial,
+                         double dt_max, double alpha0, double f_inc, double f_dec, int nmin, int use_cells,
+                         int nthreads, int *converged, double *energy, double *f_rms)
+{
+    size_t tot = (size_t)n * dim;
+    double *v = (double *)calloc(tot, sizeof(double));
+    double invL[3];
+    for (int c = 0; c < dim; ++c) invL[c] = 1.0 / L[c];
+    double alpha = alpha0, dt = dt_initial, ndof = dim * (n - 1.0);
+    int since_neg = 0, steps = 0;
+    double U = 0.0, W = 0.0, fn = 0.0;
+    *converged = 0;
+    for (int step = 1; step <= max_steps + 1; ++step) {
+        if (use_cells)
+            oracle_forces_cells(dim, n, x, L, cutoff, pot, diam, f, &U, &W, nthreads);
+        else
+            oracle_forces_brute(dim, n, x, L, cutoff, pot, diam, f, &U, &W, NULL, 0);
+        double s2 = 0.0;
+        for (int i = 0; i < n; ++i) {
+            double s = 0.0;
+            for (int c = 0; c < dim; ++c) s += f[(size_t)i * dim + c] * f[(size_t)i * dim + c];
+            s2 += s;
+        }
+        fn = sqrt(s2);
+        if (step == max_steps + 1) break; /* the closing evaluation of a run that did not converge */
+        ++steps;
+        if (fn / sqrt(ndof) < tol) {
+            *converged = 1;
+            break;
+        }
+        for (size_t k = 0; k < tot; ++k) v[k] += dt * f[k];
+        double P = 0.0, v2 = 0.0;
+        for (int i = 0; i < n; ++i) {
+            double pd = 0.0, s = 0.0;
+            for (int c = 0; c < dim; ++c) {
+                size_t k = (size_t)i * dim + c;
+                pd += v[k] * f[k];
+                s += v[k] * v[k];
+            }
+            P += pd;
+            v2 += s;
+        }
+        double vn = sqrt(v2);
+        if (vn > 0.0 && fn > 0.0) {
+            double scale = alpha * (vn / fn);
+            for (size_t k = 0; k < tot; ++k) v[k] = (1.0 - alpha) * v[k] + scale * f[k];
+        }
+        if (P > 0.0) {
+            since_neg += 1;
+            if (since_neg > nmin) {
+                dt = fmin(dt * f_inc, dt_max);
+                alpha *= 0.99;
+            }
+        } else {
+            dt = fmax(dt * f_dec, dt_initial);
+            memset(v, 0, tot * sizeof(double));
+            alpha = alpha0;
+            since_neg = 0;
+        }
+        for (int i = 0; i < n; ++i)
+            for (int c = 0; c < dim; ++c) {
+                size_t k = (size_t)i * dim + c;
+                x[k] += dt * v[k];
+                x[k] = wrap1(x[k], &img[k], L[c], invL[c]);
+            }
+    }
+    free(v);
+    *energy = U;
+    *f_rms = fn / sqrt(ndof);
+    return steps;
+}
+
 int oracle_max_threads(void)
 {
 #ifdef _OPENMP

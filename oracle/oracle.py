@@ -181,3 +181,23 @@ def bussi(v, ktemp, nf, dt, tau, r1, r2):
 
 def max_threads():
     return lib().oracle_max_threads()
+
+
+def fire_minimize(x, img, diam, box, cutoff, pot, max_steps=10000, tol=1e-6, dt_initial=0.01, dt_max=0.1, alpha0=0.1,
+                  f_inc=1.2, f_dec=0.2, nmin=5, use_cells=True, nthreads=2):
+    """fire_minimize! (src/minimize.jl:31-135) on copies; returns dict(x, img, f, steps, converged, energy, f_rms).
+    (nthreads: thousands of small force evaluations -- a few threads, not every core of a shared box.)"""
+    x = _f64(x).copy()
+    img = np.ascontiguousarray(img, dtype=np.int32).copy()
+    n, d = x.shape
+    f = np.zeros_like(x)
+    conv = C.c_int()
+    en = C.c_double()
+    frms = C.c_double()
+    fn = lib().oracle_fire_minimize
+    fn.restype = C.c_int
+    steps = fn(C.c_int(d), C.c_int(n), _d(x), _i(img), _d(f), _d(_f64(diam)), _d(_f64(box)), C.c_double(cutoff),
+               C.byref(pot), C.c_int(max_steps), C.c_double(tol), C.c_double(dt_initial), C.c_double(dt_max),
+               C.c_double(alpha0), C.c_double(f_inc), C.c_double(f_dec), C.c_int(nmin), C.c_int(1 if use_cells else 0),
+               C.c_int(nthreads), C.byref(conv), C.byref(en), C.byref(frms))
+    return dict(x=x, img=img, f=f, steps=int(steps), converged=bool(conv.value), energy=en.value, f_rms=frms.value)

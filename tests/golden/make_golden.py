@@ -54,9 +54,19 @@ def poly_case(nsteps, dt):
                 U_end=tr["U"], K_end=tr["K"], nsteps=nsteps, dt=dt, cutoff=cutoff)
 
 
+def fire_case(n, nsteps):
+    """fire_minimize! (src/minimize.jl:31-135), fixed number of steps from the thermal lattice start."""
+    s = lj_system(n, kT=1.0)
+    pot = orc.make_pot(orc.POT_LJ, [1.0, 1.0, 2.5])
+    r = orc.fire_minimize(s["x"], s["img"], s["diam"], s["box"], 2.5, pot, max_steps=nsteps, tol=1e-12, dt_initial=0.001,
+                          dt_max=0.01, use_cells=False, nthreads=1)
+    return dict(x_end=r["x"], img_end=r["img"], f_end=r["f"], energy=r["energy"], f_rms=r["f_rms"], nsteps=nsteps)
+
+
 if __name__ == "__main__":
     np.savez_compressed(os.path.join(HERE, "lj_n512_rc2p5.npz"), **lj_case(512, 2.5, 10, 0.001))
     np.savez_compressed(os.path.join(HERE, "lj_n500_rc1p5.npz"), **lj_case(500, 1.5, 10, 0.001))
     np.savez_compressed(os.path.join(HERE, "lj_n512_nvt.npz"), **nvt_case(512, 12, 0.001))
     np.savez_compressed(os.path.join(HERE, "poly2d_n1200.npz"), **poly_case(20, 0.005))
+    np.savez_compressed(os.path.join(HERE, "fire_lj_n512.npz"), **fire_case(512, 120))
     print("golden vectors written to", HERE)
