@@ -8,6 +8,8 @@ Tolerances (stated, fp64):
 The built-in LJ runs in r^-2 form on the device (no sqrt); the oracle uses the reference's
 sigma/r form -- the difference is a few ulp, inside these tolerances.
 """
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -248,6 +250,53 @@ def test_full_size_properties(n):
             assert np.array_equal(f, f0), "list strategies on one grid disagree bitwise"
         assert abs(u - u0) <= 1e-13 * abs(u0) and abs(w - w0) <= 1e-13 * abs(w0)
     assert results[3][3]["tiled"] == 0
+
+
+@pytest.mark.parametrize("n", [262144, 1048576])
+def test_full_size_vs_oracle_cells(oracle, n):
+    """BASELINE configs[1] / [2] sizes against the oracle's O(N) linked-cell path (8 OpenMP threads): forces,
+    energy, virial and the NUMBER of accepted pairs (the pair set itself is compared bit-exactly at 262144)."""
+    from moleculardynamics.jl_amd import MDDevice
+    s = lj_system(n, permute=777)
+    pot = oracle.make_pot(0, LJ)
+    f_ref, u_ref, w_ref, npairs = oracle.forces_cells(s["x"], s["box"], 2.5, pot, s["diam"], nthreads=8)
+    with MDDevice(3, n, s["box"], 2.5) as d:
+        d.set_potential(0, LJ)
+        d.upload(s["x"], s["v"], s["f"], s["img"], s["diam"])
+        u, w = d.compute_forces()
+        _, _, f, _ = d.download()
+        cnt = C.c_int64()
+        d._chk(d._L.md_neighbor_pairs(d._h, None, 0, C.byref(cnt)))
+        pairs = d.neighbor_pairs() if n <= 262144 else None
+    _check_forces(f, f_ref, 1e-11)
+    assert abs(u - u_ref) <= 1e-12 * abs(u_ref) and abs(w - w_ref) <= 1e-12 * abs(w_ref)
+    assert cnt.value == npairs
+    if pairs is not None:
+        assert np.array_equal(pairs, oracle.pairs_cells(s["x"], s["box"], 2.5))
+
+
+def test_nve_energy_drift_matches_oracle_262k(oracle):
+    """north_star: "energy drift within CPU-reference tolerance".  40 NVE steps at N=262144 on both sides from the
+    same start: the total energy changes by the same amount (the drift is the truncated potential's, not the
+    device's), and the end states agree."""
+    from moleculardynamics.jl_amd import MDDevice
+    n, nsteps, dt = 262144, 40, 0.001
+    s = lj_system(n)
+    pot = oracle.make_pot(0, LJ)
+    f0, u0, _, _ = oracle.forces_cells(s["x"], s["box"], 2.5, pot, s["diam"], nthreads=8)
+    k0 = oracle.kinetic(s["v"])
+    ref = oracle.run(s["x"], s["img"], s["v"], f0, s["diam"], s["box"], 2.5, pot, dt, nsteps, nthreads=8)
+    with MDDevice(3, n, s["box"], 2.5) as d:
+        d.set_potential(0, LJ)
+        d.upload(s["x"], s["v"], f0, s["img"], s["diam"])
+        U, W, K = d.run(nsteps, dt)
+        x, v, f, img = d.download()
+    e0 = u0 + k0
+    drift_ref = (ref["U"] + ref["K"]) - e0
+    drift_dev = (U + K) - e0
+    assert abs(drift_dev - drift_ref) <= 1e-9 * abs(e0)
+    assert abs(drift_ref) < 1e-2 * abs(e0)   # (the unshifted cutoff: -0.016 per pair that crosses r_c while the lattice melts)
+    assert np.abs(x - ref["x"]).max() <= 1e-9 and np.abs(v - ref["v"]).max() <= 1e-9 and np.array_equal(img, ref["img"])
 
 
 def test_nve_momentum_and_energy_262k():
