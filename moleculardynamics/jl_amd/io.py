@@ -2,11 +2,14 @@
 
 Out of the GPU scope -- kept minimal so run_simulation leaves
 the same files behind as the reference: extended-XYZ (src/io.jl:42-70), LAMMPS dump with
-unwrapped coordinates (src/io.jl:96-170), reader (src/io.jl:176-205).  zstd compression
-(src/io.jl:207-223) is not provided (CodecZstd has no counterpart in this image).
+unwrapped coordinates (src/io.jl:96-170), reader (src/io.jl:176-205), the log-spaced snapshot schedule
+(src/io.jl:1-36) and zstd post-compression (src/io.jl:207-223, through pyarrow's zstd codec when present).
+AsyncWriter takes the formatting and writing of a downloaded frame off the stepping thread.
 """
 import os
+import queue
 import re
+import threading
 
 import numpy as np
 
@@ -88,3 +91,76 @@ def open_files(pathname, traj_name, thermo_name):
         if os.path.isfile(f):
             os.remove(f)
     return trajectory_file, thermo_file
+
+
+def save_log_times_to_file(logs, logn, logbase, filename):
+    """src/io.jl:1-15"""
+    with open(filename, "w") as f:
+        f.write(f"#maxsnap={logn},base={logbase}\n")
+        for v in logs:
+            f.write(f"{int(v)}\n")
+
+
+def generate_log_times(max_iter=10000, logn=40, logbase=1.35, filename="new-log-times.txt"):
+    """src/io.jl:17-36: floor(j*floor(base^logn) + base^i) for j in 0..max_iter, i in 0..logn, unique and sorted;
+    also written to `filename` (the reference writes "new-log-times.txt" into the working directory)."""
+    maxlog = int(np.floor(logbase ** logn))
+    j = np.arange(max_iter + 1, dtype=np.float64)[:, None]
+    i = np.arange(logn + 1, dtype=np.float64)[None, :]
+    logs = np.unique(np.floor(j * maxlog + logbase ** i).astype(np.int64))
+    if filename:
+        save_log_times_to_file(logs, logn, logbase, filename)
+    return [int(v) for v in logs]
+
+
+def compress_zstd(filepath):
+    """src/io.jl:207-223: <file> -> <file>.zst (a standard zstd frame), the original removed."""
+    try:
+        import pyarrow as pa
+    except ImportError as e:                                        # pragma: no cover
+        raise NotImplementedError("zstd compression needs pyarrow (its zstd codec) in this build") from e
+    if not pa.Codec.is_available("zstd"):                           # pragma: no cover
+        raise NotImplementedError("this pyarrow has no zstd codec")
+    out = filepath + ".zst"
+    with open(filepath, "rb") as src, pa.CompressedOutputStream(out, "zstd") as dst:
+        while True:
+            chunk = src.read(1 << 24)
+            if not chunk:
+                break
+            dst.write(chunk)
+    os.remove(filepath)
+
+
+class AsyncWriter:
+    """One background thread that runs queued write jobs in order (at most `depth` frames in flight), so that
+    formatting a frame of text -- seconds at a million particles -- overlaps the next segment of steps.
+    Exceptions of a job are re-raised by the next submit() or by close()."""
+
+    def __init__(self, depth=2):
+        self._q = queue.Queue(maxsize=depth)
+        self._err = None
+        self._t = threading.Thread(target=self._loop, daemon=True)
+        self._t.start()
+
+    def _loop(self):
+        while True:
+            job = self._q.get()
+            if job is None:
+                return
+            fn, args, kw = job
+            try:
+                if self._err is None:
+                    fn(*args, **kw)
+            except BaseException as e:                              # noqa: BLE001
+                self._err = e
+
+    def submit(self, fn, *args, **kw):
+        if self._err is not None:
+            raise self._err
+        self._q.put((fn, args, kw))
+
+    def close(self):
+        self._q.put(None)
+        self._t.join()
+        if self._err is not None:
+            raise self._err

@@ -37,10 +37,6 @@ def run_simulation(state, params, ensemble, total_steps, frequency, pathname, tr
     """Python spelling of run_simulation! (mutates `state`, returns None)."""
     if isinstance(ensemble, Brownian):
         raise NotImplementedError("Brownian dynamics is out of scope (broken in the reference, SURVEY.md D9)")
-    if log_times:
-        raise NotImplementedError("log-spaced snapshots (src/simulation.jl:153-171) are not provided")
-    if compress:
-        raise NotImplementedError("zstd compression (src/io.jl:207-223) is not provided in this image")
     os.makedirs(pathname, exist_ok=True)
     trajectory_file, thermo_file = _io.open_files(pathname, traj_name, thermo_name)
     with open(thermo_file, "a") as io:
@@ -69,13 +65,25 @@ def run_simulation(state, params, ensemble, total_steps, frequency, pathname, tr
             r1, r2 = draw_bussi(state.nf, state.rng, nsteps)
         return dev.run(nsteps, params.dt, ens_kind, tau, state.nf, kt, r1, r2, thermo=True)
 
+    # log-spaced snapshots (src/simulation.jl:80-87,153-171): step 0 plus generate_log_times()
+    snapshot_times, snap_i = None, 0
+    if log_times:
+        snapshot_times = [0] + _io.generate_log_times()
+    writer = _io.AsyncWriter()      # frames are formatted and written while the next segment runs
+
     step = 0
     while step < total_steps:
-        # run up to and including the next output step
+        # run up to and including the next output step (thermo / trajectory cadence, or a snapshot time)
         next_out = step if step % frequency == 0 else (step // frequency + 1) * frequency
+        if snapshot_times is not None:
+            while snap_i < len(snapshot_times) and snapshot_times[snap_i] < step:
+                snap_i += 1
+            if snap_i < len(snapshot_times):
+                next_out = min(next_out, snapshot_times[snap_i])
         last = min(next_out, total_steps - 1)
         U, W, K = segment(step, last - step + 1)
         step = last + 1
+        frame = None
         if last % frequency == 0:
             temperature = 2.0 * K / state.nf
             total_energy = (U + pot.energy_lrc(n, volume)) / n          # src/simulation.jl:433-437
@@ -86,10 +94,16 @@ def run_simulation(state, params, ensemble, total_steps, frequency, pathname, tr
             state.system.energy_and_forces.energy = U
             state.system.energy_and_forces.virial = W
             if write_trajectory:
-                x, _, _, img = dev.download()
-                _io.write_to_file_lammps(trajectory_file, last, state.unitcell, n, x, img, state.diameters, dim,
-                                         mode="a")
+                x, _, _, img = frame = dev.download()
+                writer.submit(_io.write_to_file_lammps, trajectory_file, last, state.unitcell, n, x, img,
+                              state.diameters, dim, mode="a")
+        if snapshot_times is not None and snap_i < len(snapshot_times) and snapshot_times[snap_i] == last:
+            x, _, _, img = frame if frame is not None else dev.download()
+            writer.submit(_io.write_to_file_lammps, os.path.join(pathname, f"snapshot.{last}"), last, state.unitcell,
+                          n, x, img, state.diameters, dim, mode="w")
+            snap_i += 1
 
+    writer.close()
     x, v, f, img = dev.download()
     state.system.positions = x
     state.system.xpositions = x
@@ -99,4 +113,6 @@ def run_simulation(state, params, ensemble, total_steps, frequency, pathname, tr
     # finalize_simulation!: src/simulation.jl:11-36
     _io.write_to_file(os.path.join(pathname, "final.xyz"), total_steps, state.unitcell, n, x, state.diameters, dim,
                       mode="w")
+    if compress and os.path.isfile(trajectory_file):
+        _io.compress_zstd(trajectory_file)
     return None

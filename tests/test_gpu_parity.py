@@ -355,6 +355,32 @@ def test_run_simulation_readme_example(tmp_path, potname):
     state.system.device.close()
 
 
+def test_run_simulation_log_snapshots_and_zstd(tmp_path, monkeypatch):
+    """The output path either side of the step loop: LAMMPS frames at `frequency`
+    cadence, log-spaced snapshot files (src/simulation.jl:153-171), zstd post-compression of the trajectory
+    (src/simulation.jl:11-36), all written by the background writer."""
+    import pyarrow as pa
+    import moleculardynamics.jl_amd as md
+    monkeypatch.chdir(tmp_path)                       # generate_log_times writes new-log-times.txt into the cwd
+    params = md.Parameters(0.8, 512, 0.001, md.LennardJones())
+    path = str(tmp_path / "out")
+    state = md.initialize_state(params, path, random_init=True, cutoff=2.5, rng=np.random.default_rng(5))
+    state.velocities = md.initialize_velocities(1.0, np.random.default_rng(6), 512, 3)
+    md.run_simulation(state, params, md.NVE(), 30, 10, path, compress=True, log_times=True)
+    # floor(1.35^i), i = 0..40, below 30: 1 2 3 4 6 8 11 14 20 27  (+ step 0)
+    snaps = sorted(int(f.split(".")[1]) for f in os.listdir(path) if f.startswith("snapshot."))
+    assert snaps == [0, 1, 2, 3, 4, 6, 8, 11, 14, 20, 27]
+    assert os.path.isfile(tmp_path / "new-log-times.txt")
+    first = open(os.path.join(path, "snapshot.6")).read().splitlines()
+    assert first[0] == "ITEM: TIMESTEP" and first[1] == "6" and first[3] == "512"
+    assert not os.path.exists(os.path.join(path, "trajectory.xyz"))
+    raw = pa.CompressedInputStream(os.path.join(path, "trajectory.xyz.zst"), "zstd").read().decode()
+    assert raw.count("ITEM: TIMESTEP") == 3           # steps 0, 10, 20
+    rows = open(os.path.join(path, "thermo.txt")).read().splitlines()
+    assert [int(r.split()[0]) for r in rows[1:]] == [0, 10, 20]
+    state.system.device.close()
+
+
 import re  # noqa: E402
 re_float = re.compile(r"^-?\d+\.\d{6}$")
 

@@ -169,3 +169,33 @@ def test_run_simulation_rejects_out_of_scope():
     p = md.Parameters(0.9, 10, 0.001, md.LennardJones())
     with pytest.raises(NotImplementedError, match="Brownian"):
         md.run_simulation(st, p, md.Brownian(1.0), 10, 1, "/tmp/x")
+
+
+def test_log_times_schedule(tmp_path):
+    """src/io.jl:17-36 on a hand-checkable case: base 1.35, logn 5 -> floor(1.35^5) = 4; j = 0..2 gives 1..12."""
+    from moleculardynamics.jl_amd import io
+    f = tmp_path / "t.txt"
+    logs = io.generate_log_times(max_iter=2, logn=5, logbase=1.35, filename=str(f))
+    assert logs == list(range(1, 13))
+    txt = f.read_text().splitlines()
+    assert txt[0] == "#maxsnap=5,base=1.35" and [int(v) for v in txt[1:]] == logs
+    full = io.generate_log_times(filename=None)
+    assert full[:10] == [1, 2, 3, 4, 6, 8, 11, 14, 20, 27] and full == sorted(set(full))
+
+
+def test_zstd_roundtrip_and_async_writer(tmp_path):
+    pa = pytest.importorskip("pyarrow")
+    from moleculardynamics.jl_amd import io
+    p = tmp_path / "a.txt"
+    w = io.AsyncWriter()
+    for k in range(5):                                  # jobs run in submission order
+        w.submit(lambda k=k: open(p, "a").write(f"line {k}\n"))
+    w.close()
+    assert p.read_text().splitlines() == [f"line {k}" for k in range(5)]
+    io.compress_zstd(str(p))
+    assert not p.exists()
+    assert pa.CompressedInputStream(str(p) + ".zst", "zstd").read().decode().splitlines()[4] == "line 4"
+    w = io.AsyncWriter()
+    w.submit(lambda: 1 / 0)
+    with pytest.raises(ZeroDivisionError):
+        w.close()
