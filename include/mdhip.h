@@ -31,8 +31,12 @@ typedef struct md_ctx md_ctx;
  *                          sigma comes from the two diameters)
  *   MD_POT_PSEUDOHS      {lambda}                  src/potentials.jl:1-29
  *   MD_POT_POLYDISPERSE  {r_cut, non_additivity}   README.md:89-145 (user potential example)
+ *   MD_POT_LJ_MODIFIED   {epsilon, sigma, r_cut, mode, r_on}  the reference's shifted (mode 0,
+ *                         src/potentials.jl:79-90), force-shifted (1, :92-103) and XPLOR-switched (2,
+ *                         :195-238) Lennard-Jones: dead code there (evaluate never dispatches to them),
+ *                         reachable here.  V_cut, F_cut follow the constructor (:52-64).
  *   MD_POT_CUSTOM        set through md_set_potential_source (hiprtc)                      */
-enum { MD_POT_LJ = 0, MD_POT_PSEUDOHS = 1, MD_POT_POLYDISPERSE = 2, MD_POT_CUSTOM = 100 };
+enum { MD_POT_LJ = 0, MD_POT_PSEUDOHS = 1, MD_POT_POLYDISPERSE = 2, MD_POT_LJ_MODIFIED = 3, MD_POT_CUSTOM = 100 };
 
 /* Ensemble kinds for md_run: src/types.jl:34-51, src/integrate.jl:40-53 */
 enum { MD_NVE = 0, MD_NVT = 1 };

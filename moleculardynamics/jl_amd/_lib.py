@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "csrc", "libmdhip.so")
 
-MD_POT_LJ, MD_POT_PSEUDOHS, MD_POT_POLYDISPERSE, MD_POT_CUSTOM = 0, 1, 2, 100
+MD_POT_LJ, MD_POT_PSEUDOHS, MD_POT_POLYDISPERSE, MD_POT_LJ_MODIFIED, MD_POT_CUSTOM = 0, 1, 2, 3, 100
 MD_NVE, MD_NVT = 0, 1
 
 # every symbol include/mdhip.h declares

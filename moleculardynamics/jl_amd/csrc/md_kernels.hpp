@@ -29,7 +29,7 @@ typedef __hip_internal::uint16_t uint16_t;
 #define MD_VAL_SRC_MASK ((1u << MD_VAL_SRC_BITS) - 1u)
 #define MD_NO_VIOLATION 0x7fffffff
 
-enum { POT_LJ = 0, POT_PSEUDOHS = 1, POT_POLYDISPERSE = 2, POT_CUSTOM = 100 };
+enum { POT_LJ = 0, POT_PSEUDOHS = 1, POT_POLYDISPERSE = 2, POT_LJ_MOD = 3, POT_CUSTOM = 100 };
 
 struct DevState {
     double4 *pos;  // cap+1 records (x, y, z, diameter): owned [0,n), ghosts [n,next), sentinel at cap.
@@ -268,6 +268,48 @@ __device__ __forceinline__ void pair_eval(double d2, double si, double sj, const
             uij = 134.5526623421209 * (pl - plm) + 1.0;
             fij = lambda * (pl * sr) - (lambda - 1.0) * pl;
             fij *= 134.5526623421209;
+        }
+        u = uij;
+        fpr = fij / r;
+    } else if constexpr (POT == POT_LJ_MOD) {
+        // the reference's shifted / force-shifted / XPLOR Lennard-Jones (src/potentials.jl:79-103,195-238), dead
+        // code there, reachable here.  p = {eps, sigma_ctor, r_cut, mode, r_on, V_cut, F_cut};
+        // V_cut, F_cut are the constructor's constants (src/potentials.jl:52-64: from the struct's sigma).
+        double r = sqrt(d2);
+        double sg = UNIFORM ? pp.sig_u : (si + sj) / 2.0;
+        double eps = pp.p[0], rc = pp.p[2];
+        int mode = (int)pp.p[3];
+        double uij = 0.0, fij = 0.0;
+        if (r < rc) {
+            double sr = sg / r;
+            double sr2 = sr * sr;
+            double sr6 = (sr2 * sr2) * sr2;
+            double sr12 = sr6 * sr6;
+            double V = (4.0 * eps) * (sr12 - sr6);
+            double F = ((24.0 * eps) * (2.0 * sr12 - sr6)) / r;
+            if (mode == 0) { // lj_energy_shifted :79-90
+                uij = V - pp.p[5];
+                fij = F;
+            } else if (mode == 1) { // lj_force_shifted :92-103 -- with +(r - rc) F_cut: the reference text has "-",
+                                    // which is not the potential of its own force F - F_cut (dead code there)
+                uij = V - pp.p[5] + (r - rc) * pp.p[6];
+                fij = F - pp.p[6];
+            } else { // lj_xplor + xplor_switch :195-238
+                double ron = pp.p[4];
+                double S = 1.0, dS = 0.0;
+                if (r >= ron) {
+                    double rc2 = rc * rc, r2 = r * r, ron2 = ron * ron;
+                    double den = ((rc2 - ron2) * (rc2 - ron2)) * (rc2 - ron2);
+                    double a = rc2 - r2, b = rc2 + 2.0 * r2 - 3.0 * ron2;
+                    S = ((a * a) * b) / den;
+                    dS = (-12.0 * r * a * (r2 - ron2)) / den;
+                }
+                uij = V * S;
+                // f = -d(V S)/dr = S F - V dS/dr.  The reference's (never executed) expressions differ: its dS/dr
+                // has two terms that cancel, leaving 4r(rc^2-r^2)^2/den, and it adds V dS (:209-214,233-235);
+                // neither is the derivative of its own S and V S, so the consistent form is implemented instead.
+                fij = S * F - V * dS;
+            }
         }
         u = uij;
         fpr = fij / r;

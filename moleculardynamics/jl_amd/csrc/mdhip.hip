@@ -349,7 +349,7 @@ void configure_potential(md_ctx *c)
 {
     double c2_incl = c->rc * c->rc;
     double c2 = std::nextafter(c2_incl, INFINITY); // d2 < c2  <=>  d2 <= rc^2
-    if (c->pot_kind == POT_LJ) {
+    if (c->pot_kind == POT_LJ || c->pot_kind == POT_LJ_MOD) {
         // r >= r_cut -> (0,0): src/potentials.jl:67-69
         double rcp2 = c->pp.p[2] * c->pp.p[2];
         c2 = std::min(c2, rcp2);
@@ -469,7 +469,7 @@ void rebuild_t(md_ctx *c)
     c->use_tiles = false;
     c->have_nlist32 = false;
     bool tile_ok = false;
-    const int rs = (c->uniform_sigma && c->pot_kind != POT_POLYDISPERSE && c->pot_kind != POT_CUSTOM) ? 24 : 32; // LDS record stride of the tiled force kernel
+    const int rs = (c->uniform_sigma && c->pot_kind != POT_POLYDISPERSE && c->pot_kind != POT_LJ_MOD && c->pot_kind != POT_CUSTOM) ? 24 : 32; // LDS record stride of the tiled force kernel
     auto set_tiles = [&](const Scalars &h) {
         size_t bytes = ((size_t)(h.hmax + 1) * rs + 15) & ~(size_t)15;
         if (!(h.halo_overflow) && bytes <= 150 * 1024) {
@@ -746,6 +746,9 @@ void launch_force_d(md_ctx *c, bool want_uw, bool kick, double dt, int step, int
     case POT_POLYDISPERSE:
         launch_force_tpu<D, POT_POLYDISPERSE, false>(c, want_uw, kick, dt, step, rows);
         break;
+    case POT_LJ_MOD:
+        launch_force_tpu<D, POT_LJ_MOD, false>(c, want_uw, kick, dt, step, rows);
+        break;
     case POT_CUSTOM:
         launch_force_custom(c, D, want_uw, kick, dt, step);
         break;
@@ -1000,12 +1003,22 @@ int md_destroy(md_ctx *ctx)
 int md_set_potential(md_ctx *ctx, int kind, const double *params, int nparams)
 {
     API_BEGIN
-    if (kind != MD_POT_LJ && kind != MD_POT_PSEUDOHS && kind != MD_POT_POLYDISPERSE)
+    if (kind != MD_POT_LJ && kind != MD_POT_PSEUDOHS && kind != MD_POT_POLYDISPERSE && kind != MD_POT_LJ_MODIFIED)
         throw HipError("md_set_potential: unknown potential kind");
     if (nparams < 0 || nparams > 8 || (nparams > 0 && !params)) throw HipError("md_set_potential: bad params");
-    int need = (kind == MD_POT_LJ) ? 3 : (kind == MD_POT_PSEUDOHS ? 1 : 2);
+    int need = (kind == MD_POT_LJ) ? 3 : (kind == MD_POT_PSEUDOHS ? 1 : (kind == MD_POT_LJ_MODIFIED ? 5 : 2));
     if (nparams < need) throw HipError("md_set_potential: too few parameters for this kind");
     for (int i = 0; i < 8; ++i) ctx->pp.p[i] = (i < nparams) ? params[i] : 0.0;
+    if (kind == MD_POT_LJ_MODIFIED) {
+        // the constructor's constants: src/potentials.jl:52-64 (from the struct's sigma and r_cut)
+        double eps = params[0], sg = params[1], rc = params[2];
+        int mode = (int)params[3];
+        if (mode < 0 || mode > 2) throw HipError("md_set_potential: MD_POT_LJ_MODIFIED mode must be 0, 1 or 2");
+        if (mode == 2 && !(params[4] < rc)) throw HipError("md_set_potential: XPLOR needs r_on < r_cut");
+        double s = sg / rc, s2 = s * s, s6 = s2 * s2 * s2, s12 = s6 * s6;
+        ctx->pp.p[5] = 4.0 * eps * (s12 - s6);
+        ctx->pp.p[6] = 24.0 * eps * (2.0 * s12 - s6) / rc;
+    }
     ctx->pot_kind = kind;
     ctx->list_valid = false; // the LDS record stride of the rows depends on the potential kind
     configure_potential(ctx);

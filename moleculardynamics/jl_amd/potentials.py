@@ -104,3 +104,85 @@ class Polydisperse(Potential):
 
     def device_spec(self):
         return ("builtin", _lib.MD_POT_POLYDISPERSE, [self.rcut, self.non_additivity])
+
+
+class _ModifiedLJ(LennardJones):
+    """The reference's shifted / force-shifted Lennard-Jones (src/potentials.jl:79-103).  In the reference
+    `LennardJones(shift=true)` still evaluates the unshifted branch; these classes make the
+    variants reachable explicitly, with the constructor's V_cut / F_cut (from the struct's sigma, :52-64)."""
+    _mode = 0
+
+    def evaluate(self, r, sigma1, sigma2):
+        if r >= self.r_cut:
+            return 0.0, 0.0
+        u, f = LennardJones.evaluate(self, r, sigma1, sigma2)
+        if self._mode == 0:
+            return u - self.V_cut, f
+        # (+: the reference text has "-", which is not the potential of its own force F - F_cut; dead code there)
+        return u - self.V_cut + (r - self.r_cut) * self.F_cut, f - self.F_cut
+
+    def device_spec(self):
+        return ("builtin", _lib.MD_POT_LJ_MODIFIED, [self.epsilon, self.sigma, self.r_cut, float(self._mode), 0.0])
+
+
+class LennardJonesShifted(_ModifiedLJ):
+    """lj_energy_shifted, src/potentials.jl:79-90:  V - V_cut, force unchanged."""
+    _mode = 0
+
+
+class LennardJonesForceShifted(_ModifiedLJ):
+    """lj_force_shifted, src/potentials.jl:92-103:  V - V_cut + (r - r_cut) F_cut,  F - F_cut (sign of the linear
+    term corrected so that f = -dU/dr)."""
+    _mode = 1
+
+
+class LennardJonesXPLOR(Potential):
+    """src/potentials.jl:176-249, positional evaluate (the reference's keyword form cannot be called from the pair
+    loop).  Deviation, stated: the reference's switch derivative and force sign (:209-214,233-235)
+    are not the derivative of its own V*S; the consistent f = S F - V dS/dr is used on host, device and oracle."""
+
+    def __init__(self, epsilon=1.0, sigma=1.0, r_on=2.0, r_cut=2.5, tail_correction=False):
+        self.epsilon, self.sigma, self.r_on, self.r_cut = float(epsilon), float(sigma), float(r_on), float(r_cut)
+        self.tail_correction = bool(tail_correction)
+        if not self.r_on < self.r_cut:
+            raise ValueError("LennardJonesXPLOR needs r_on < r_cut")
+
+    def switch(self, r):
+        """xplor_switch: (S, dS/dr)"""
+        if r < self.r_on:
+            return 1.0, 0.0
+        if r < self.r_cut:
+            rc2, r2, ron2 = self.r_cut ** 2, r * r, self.r_on ** 2
+            den = (rc2 - ron2) ** 3
+            S = (rc2 - r2) ** 2 * (rc2 + 2.0 * r2 - 3.0 * ron2) / den
+            return S, -12.0 * r * (rc2 - r2) * (r2 - ron2) / den
+        return 0.0, 0.0
+
+    def evaluate(self, r, sigma1, sigma2):
+        if r >= self.r_cut:
+            return 0.0, 0.0
+        sigma = (sigma1 + sigma2) / 2.0
+        sr = sigma / r
+        sr2 = sr * sr
+        sr6 = (sr2 * sr2) * sr2
+        sr12 = sr6 * sr6
+        V = 4.0 * self.epsilon * (sr12 - sr6)
+        F = 24.0 * self.epsilon * (2.0 * sr12 - sr6) / r
+        S, dS = self.switch(r)
+        return V * S, S * F - V * dS
+
+    def device_spec(self):
+        return ("builtin", _lib.MD_POT_LJ_MODIFIED, [self.epsilon, self.sigma, self.r_cut, 2.0, self.r_on])
+
+    # src/potentials.jl:251-313
+    def energy_lrc(self, n, volume):
+        if not self.tail_correction:
+            return 0.0
+        rho, s, rc = n / volume, self.sigma, self.r_cut
+        return (8.0 / 3.0) * math.pi * rho * n * self.epsilon * s ** 3 * ((1.0 / 3.0) * (s / rc) ** 9 - (s / rc) ** 3)
+
+    def pressure_lrc(self, n, volume):
+        if not self.tail_correction:
+            return 0.0
+        rho, s, rc = n / volume, self.sigma, self.r_cut
+        return (16.0 / 3.0) * math.pi * rho ** 2 * self.epsilon * s ** 3 * ((2.0 / 3.0) * (s / rc) ** 9 - (s / rc) ** 3)

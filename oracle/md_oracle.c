@@ -41,6 +41,7 @@
 #define POT_LJ 0
 #define POT_PSEUDOHS 1
 #define POT_POLYDISPERSE 2
+#define POT_LJ_MODIFIED 3 /* p = {eps, sigma_ctor, r_cut, mode (0 shifted, 1 force-shifted, 2 XPLOR), r_on} */
 
 typedef struct {
     int kind;
@@ -131,6 +132,48 @@ void oracle_evaluate(const oracle_pot *pot, double r, double s1, double s2, doub
         double se = 0.5 * (s1 + s2);
         se *= (1.0 - pot->p[1] * fabs(s1 - s2));
         poly_potential(r, se, pot->p[0], u, f);
+        break;
+    }
+    case POT_LJ_MODIFIED: {
+        /* src/potentials.jl:79-90 (lj_energy_shifted), :92-103 (lj_force_shifted), :195-238 (xplor_switch,
+         * lj_xplor); V_cut, F_cut as the constructor computes them, :52-64 (from the struct's sigma) */
+        double sigma = (s1 + s2) / 2.0;
+        double eps = pot->p[0], sc = pot->p[1], rc = pot->p[2], ron = pot->p[4];
+        int mode = (int)pot->p[3];
+        double srcut = sc / rc, srcut2 = srcut * srcut, srcut6 = srcut2 * srcut2 * srcut2, srcut12 = srcut6 * srcut6;
+        double Vcut = 4.0 * eps * (srcut12 - srcut6);
+        double Fcut = 24.0 * eps * (2.0 * srcut12 - srcut6) / rc;
+        if (r >= rc) {
+            *u = 0.0;
+            *f = 0.0;
+            break;
+        }
+        double sr = sigma / r, sr2 = sr * sr, sr6 = (sr2 * sr2) * sr2, sr12 = sr6 * sr6;
+        double V = (4.0 * eps) * (sr12 - sr6);
+        double F = ((24.0 * eps) * (2.0 * sr12 - sr6)) / r;
+        if (mode == 0) {
+            *u = V - Vcut;
+            *f = F;
+        } else if (mode == 1) {
+            /* DEVIATION from the (never executed) reference text, :100: "- (r - r_cut) * Fcut" is not the
+             * potential of its own force F - Fcut; the consistent V - Vcut + (r - r_cut) Fcut is used. */
+            *u = V - Vcut + (r - rc) * Fcut;
+            *f = F - Fcut;
+        } else {
+            double S = 1.0, dS = 0.0;
+            if (r >= ron) {
+                double rc2 = rc * rc, r2 = r * r, ron2 = ron * ron;
+                double den = ((rc2 - ron2) * (rc2 - ron2)) * (rc2 - ron2);
+                double num1 = ((rc2 - r2) * (rc2 - r2)) * (rc2 + 2.0 * r2 - 3.0 * ron2);
+                S = num1 / den;
+                /* DEVIATION from the (never executed) reference text: its dS/dr (:209-214) has two terms that
+                 * cancel, leaving 4r(rc^2-r^2)^2/den, and its force adds V dS (:233-235); neither is the
+                 * derivative of its own S and V*S.  The consistent f = -d(V S)/dr = S F - V dS/dr is used. */
+                dS = (-12.0 * r * (rc2 - r2) * (r2 - ron2)) / den;
+            }
+            *u = V * S;
+            *f = S * F - V * dS;
+        }
         break;
     }
     default:

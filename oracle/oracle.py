@@ -13,7 +13,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libmdoracle.so")
 
-POT_LJ, POT_PSEUDOHS, POT_POLYDISPERSE = 0, 1, 2
+POT_LJ, POT_PSEUDOHS, POT_POLYDISPERSE, POT_LJ_MODIFIED = 0, 1, 2, 3
 
 
 class OraclePot(C.Structure):

@@ -355,6 +355,36 @@ def test_run_simulation_readme_example(tmp_path, potname):
     state.system.device.close()
 
 
+@pytest.mark.parametrize("mode,ron", [(0, 0.0), (1, 0.0), (2, 2.0)])
+def test_modified_lj_kinds(oracle, mode, ron):
+    """MD_POT_LJ_MODIFIED (shifted / force-shifted / XPLOR) against the oracle, with
+    per-particle diameters; and the point of a force-shifted potential: NVE energy is conserved far better
+    than with the truncated one."""
+    from moleculardynamics.jl_amd import MDDevice
+    n = 1000
+    s = lj_system(n, kT=1.0)
+    rng = np.random.default_rng(11)
+    diam = rng.uniform(0.9, 1.1, n)
+    params = [1.0, 1.0, 2.5, float(mode), ron]
+    pot = oracle.make_pot(oracle.POT_LJ_MODIFIED, params)
+    f_ref, u_ref, w_ref, pairs_ref = oracle.forces_brute(s["x"], s["box"], 2.5, pot, diam, want_pairs=True)
+    with MDDevice(3, n, s["box"], 2.5) as d:
+        d.set_potential(3, params)
+        d.upload(s["x"], s["v"], s["f"], s["img"], diam)
+        u, w = d.compute_forces()
+        _, _, f, _ = d.download()
+        _check_forces(f, f_ref, 1e-11)
+        assert abs(u - u_ref) <= 1e-12 * abs(u_ref) and abs(w - w_ref) <= 1e-12 * abs(w_ref)
+        ref = oracle.run(s["x"], s["img"], s["v"], f_ref, diam, s["box"], 2.5, pot, 0.001, 10, use_cells=False)
+        U, W, K = d.run(10, 0.001)
+        x, v, _, _ = d.download()
+        assert np.abs(x - ref["x"]).max() <= 1e-10 and np.abs(v - ref["v"]).max() <= 1e-10
+        if mode == 1:
+            e0 = U + K
+            U2, _, K2 = d.run(400, 0.001)
+            assert abs((U2 + K2) - e0) <= 1e-3 * abs(e0)      # (velocity-Verlet fluctuation while the lattice melts)
+
+
 def test_run_simulation_log_snapshots_and_zstd(tmp_path, monkeypatch):
     """The output path either side of the step loop: LAMMPS frames at `frequency`
     cadence, log-spaced snapshot files (src/simulation.jl:153-171), zstd post-compression of the trajectory

@@ -202,3 +202,30 @@ def test_golden_poly2d(oracle):
     f, u, w, pairs = oracle.forces_brute(s["x"], s["box"], float(g["cutoff"]), pot, s["diam"], want_pairs=True)
     assert np.array_equal(pairs, g["pairs"]) and np.array_equal(f, g["forces"])
     assert u == float(g["U"]) and w == float(g["W"])
+
+
+@pytest.mark.parametrize("mode,ron", [(0, 0.0), (1, 0.0), (2, 2.0)])
+def test_modified_lj_variants(oracle, mode, ron):
+    """Shifted / force-shifted / XPLOR LJ (src/potentials.jl:79-103,195-238; dead in the reference, reachable here):
+    host class == oracle; f = -dU/dr; the shifted forms vanish at r_cut; XPLOR is plain LJ below r_on."""
+    import moleculardynamics.jl_amd as md
+    cls = [md.LennardJonesShifted, md.LennardJonesForceShifted, None][mode]
+    host = cls(epsilon=1.3, sigma=1.0, r_cut=2.5) if cls else md.LennardJonesXPLOR(epsilon=1.3, sigma=1.0, r_on=ron, r_cut=2.5)
+    pot = oracle.make_pot(oracle.POT_LJ_MODIFIED, [1.3, 1.0, 2.5, float(mode), ron])
+    lj = oracle.make_pot(oracle.POT_LJ, [1.3, 1.0, 2.5])
+    for r, s1, s2 in [(0.95, 1.0, 1.0), (1.6, 0.9, 1.2), (2.2, 1.0, 1.0), (2.45, 1.1, 0.8), (2.5, 1.0, 1.0), (3.0, 1.0, 1.0)]:
+        u, f = oracle.evaluate(pot, r, s1, s2)
+        uh, fh = host.evaluate(r, s1, s2)
+        assert abs(u - uh) <= 1e-13 * max(1.0, abs(u)) and abs(f - fh) <= 1e-13 * max(1.0, abs(f))
+        if r < 2.5:
+            h = 1e-6
+            up, _ = oracle.evaluate(pot, r + h, s1, s2)
+            um, _ = oracle.evaluate(pot, r - h, s1, s2)
+            assert abs(f + (up - um) / (2 * h)) <= 1e-6 * max(1.0, abs(f))
+        else:
+            assert (u, f) == (0.0, 0.0)
+    eps = 1e-9
+    u, f = oracle.evaluate(pot, 2.5 - eps, 1.0, 1.0)
+    assert abs(u) < 1e-7 and (mode == 0 or abs(f) < 1e-7)
+    if mode == 2:
+        assert oracle.evaluate(pot, 1.5, 1.0, 1.0) == oracle.evaluate(lj, 1.5, 1.0, 1.0)
