@@ -12,7 +12,8 @@ using Random, Printf, LinearAlgebra, Statistics
 using Distributions: Gamma
 
 export Parameters, NVT, NVE, Potential, evaluate, LennardJones, PseudoHS, Polydisperse,
-       initialize_state, initialize_velocities, run_simulation!, LinearRamp, ExponentialRamp, fire_minimize!
+       initialize_state, initialize_velocities, run_simulation!, LinearRamp, ExponentialRamp, fire_minimize!,
+       LennardJonesShifted, LennardJonesForceShifted, LennardJonesXPLOR
 
 const LIB = get(ENV, "MDHIP_LIB", joinpath(@__DIR__, "..", "moleculardynamics", "jl_amd", "csrc", "libmdhip.so"))
 
@@ -76,6 +77,21 @@ Base.@kwdef struct Polydisperse <: Potential                                    
     non_additivity::Float64 = 0.2
 end
 device_spec(p::Polydisperse) = (2, [p.rcut, p.non_additivity])
+
+# shifted / force-shifted / XPLOR Lennard-Jones (src/potentials.jl:79-103,176-249; dead code in the reference):
+# device kind 3 = MD_POT_LJ_MODIFIED, params {epsilon, sigma, r_cut, mode, r_on}; see include/mdhip.h
+Base.@kwdef struct LennardJonesShifted <: Potential
+    epsilon::Float64 = 1.0; sigma::Float64 = 1.0; r_cut::Float64 = 2.5
+end
+Base.@kwdef struct LennardJonesForceShifted <: Potential
+    epsilon::Float64 = 1.0; sigma::Float64 = 1.0; r_cut::Float64 = 2.5
+end
+Base.@kwdef struct LennardJonesXPLOR <: Potential
+    ϵ::Float64 = 1.0; σ::Float64 = 1.0; r_on::Float64 = 2.0; r_cut::Float64 = 2.5; tail_correction::Bool = false
+end
+device_spec(p::LennardJonesShifted) = (3, [p.epsilon, p.sigma, p.r_cut, 0.0, 0.0])
+device_spec(p::LennardJonesForceShifted) = (3, [p.epsilon, p.sigma, p.r_cut, 1.0, 0.0])
+device_spec(p::LennardJonesXPLOR) = (3, [p.ϵ, p.σ, p.r_cut, 2.0, p.r_on])
 
 # ---- ramps: src/temperature_ramps.jl ----------------------------------------------------
 struct LinearRamp; T_initial::Float64; T_final::Float64; n_steps::Int; end
