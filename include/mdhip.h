@@ -119,6 +119,16 @@ int md_fire_minimize(md_ctx *ctx, int64_t max_steps, double tol, double dt_initi
                      double f_inc, double f_dec, int nmin, int64_t *steps, int *converged, double *energy,
                      double *f_rms);
 
+/* The Brownian step loop (src/simulation.jl:181-308 + integrate_brownian! src/integrate.jl:66-82; broken in the
+ * reference; restated here):  per step  forces at x ;  x += f*dt/kT + sqrt(2 dt)*noise ,
+ * noise_c = (2u-1)*sqrt(3).  The reference draws u from one host RNG shared by its threads; here u comes from a
+ * counter-based stream -- Philox4x32-10, key = seed, counter = (0-based particle index, first_step + s) --
+ * so a trajectory depends on neither thread layout nor particle order and a host can reproduce it.
+ * out = {U, W of the last step's force evaluation, sum of the virial over the steps with
+ * (first_step + s) % virial_every == 0 (the reference samples every 10th step), number of such steps}.     */
+int md_run_brownian(md_ctx *ctx, int64_t nsteps, double dt, double ktemp, uint64_t seed, int64_t first_step,
+                    int64_t virial_every, double *out /* [4] */);
+
 /* compute_kinetic: src/thermostat.jl:50-60 */
 int md_kinetic(md_ctx *ctx, double *kinetic);
 

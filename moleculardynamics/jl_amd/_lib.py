@@ -17,7 +17,7 @@ EXPORTS = [
     "md_create", "md_destroy", "md_last_error", "md_set_potential", "md_set_potential_source", "md_set_skin",
     "md_set_inner_skin",
     "md_upload", "md_download", "md_compute_forces", "md_neighbor_pairs", "md_run", "md_kinetic",
-    "md_scale_velocities", "md_profile", "md_get_stats", "md_version", "md_fire_minimize",
+    "md_scale_velocities", "md_profile", "md_get_stats", "md_version", "md_fire_minimize", "md_run_brownian",
     "md_create_domain", "md_dom_set_uniform", "md_dom_upload", "md_dom_download", "md_dom_migrate_pack",
     "md_dom_migrate_unpack", "md_dom_halo_pack", "md_dom_halo_unpack", "md_dom_build", "md_dom_get_sendbuf",
     "md_dom_put_recvbuf", "md_dom_set_step_buffers", "md_dom_step_begin", "md_dom_step_end", "md_dom_forces", "md_dom_set_scale",
@@ -88,6 +88,8 @@ def load():
     i64p = C.POINTER(C.c_int64)
     L.md_create_domain.argtypes = [C.c_int, C.c_int64, C.c_int64, dp, C.c_double, C.c_int, C.c_int, C.c_int,
                                    C.POINTER(vp)]
+    L.md_run_brownian.restype = C.c_int
+    L.md_run_brownian.argtypes = [vp, C.c_int64, C.c_double, C.c_double, C.c_uint64, C.c_int64, C.c_int64, dp]
     L.md_fire_minimize.restype = C.c_int
     L.md_fire_minimize.argtypes = [vp, C.c_int64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
                                    C.c_int, i64p, C.POINTER(C.c_int), dp, dp]

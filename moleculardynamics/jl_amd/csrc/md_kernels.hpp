@@ -1285,6 +1285,91 @@ __global__ void __launch_bounds__(MD_BLOCK)
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Brownian dynamics (src/integrate.jl:55-82, src/simulation.jl:181-308; broken in the reference):
+//   x += f*dt/kT + sigma*noise,  sigma = sqrt(2 dt),  noise_c = (2u-1)*sqrt(3), u uniform.
+// The reference shares one host RNG across threads; here the noise is a counter-based stream,
+// Philox4x32-10 keyed by the seed with counter (particle id, step): one call gives a particle's three
+// uniforms, the result depends on neither the thread layout nor the particle order, and the oracle
+// reproduces it exactly on the host.
+// ------------------------------------------------------------------------------------------
+__host__ __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                              uint32_t out[4])
+{
+    for (int r = 0; r < 10; ++r) {
+        unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0;
+        c1 = n1;
+        c2 = n2;
+        c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0;
+    out[1] = c1;
+    out[2] = c2;
+    out[3] = c3;
+}
+
+template <int D>
+__global__ void __launch_bounds__(MD_BLOCK)
+    k_brownian_move(int n, DevState s, double dt_over_kt, double sigma, unsigned long long seed, long long gstep,
+                    double skin_half, Scalars *sc, int step)
+{
+    if (sc->first_viol <= step) return;
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    double disp2 = 0.0;
+    if (k < n) {
+        uint32_t w[4];
+        philox4x32_10((uint32_t)s.id[k], (uint32_t)gstep, (uint32_t)((unsigned long long)gstep >> 32), 0u, (uint32_t)seed,
+                      (uint32_t)(seed >> 32), w);
+        double4 p = s.pos[k];
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            double u = ((double)w[c] + 0.5) * 2.3283064365386963e-10; // (w + 1/2) / 2^32, in (0,1)
+            double noise = (2.0 * u - 1.0) * 1.7320508075688772;
+            double xc = pos_get(p, c) + (s.f[c][k] * dt_over_kt) + (noise * sigma);
+            pos_set(p, c, xc);
+            double d = xc - s.x0[c][k];
+            disp2 = __builtin_fma(d, d, disp2);
+        }
+        s.pos[k] = p;
+    }
+    // the rows were built at x0 with margin 2*skin_half: the NEXT force evaluation needs a rebuild first
+    if (__any(disp2 > skin_half * skin_half)) {
+        if ((threadIdx.x & 63) == 0) atomicMin(&sc->first_viol, step + 1);
+    }
+}
+
+// fixed-order sums of the force kernel's U/W partials; virial accumulated on the steps that sample it
+// (src/simulation.jl:253-256: every 10th step)
+__global__ void __launch_bounds__(1024)
+    k_brownian_sums(int nblk, const double *__restrict__ partials, int sample_virial, double *__restrict__ acc /* [2] */,
+                    Scalars *sc, int step)
+{
+    __shared__ double red[16];
+    if (sc->first_viol <= step) return;
+    double b = 0.0, c = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += blockDim.x) {
+        b += partials[nblk + i];
+        c += partials[2 * nblk + i];
+    }
+    b = block_sum(b, red);
+    c = block_sum(c, red);
+    if (threadIdx.x == 0) {
+        sc->U = b / 2.0;
+        sc->W = c / 2.0;
+        if (sample_virial) {
+            acc[0] += c / 2.0;
+            acc[1] += 1.0;
+        }
+    }
+}
+
 __global__ void k_set_scale(Scalars *sc, double v) { sc->scale = v; }
 __global__ void k_set_scale_unless_violated(Scalars *sc, double v)
 {

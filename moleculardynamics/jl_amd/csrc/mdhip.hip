@@ -159,6 +159,7 @@ struct md_ctx {
     DBuf<double> partials;
     DBuf<double> fire_part;      // FIRE: per-block sums of |f|^2, v.f, |v|^2
     DBuf<FireState> fire_state;
+    DBuf<double> brown_acc;      // Brownian: {sum of sampled virials, number of samples}
     int nblk = 0;
     DBuf<Scalars> scal;
     DBuf<double> d_kt, d_r1, d_r2;
@@ -1511,6 +1512,68 @@ int md_fire_minimize(md_ctx *ctx, int64_t max_steps, double tol, double dt_initi
     if (converged) *converged = conv ? 1 : 0;
     if (energy) *energy = hf.energy;
     if (f_rms) *f_rms = hf.f_rms;
+    API_END
+}
+
+// Brownian dynamics: the step loop of src/simulation.jl:181-308 (forces at x, then the Euler-Maruyama move of
+// src/integrate.jl:66-82), device resident; noise from Philox keyed by (seed; particle id, first_step + s).
+int md_run_brownian(md_ctx *ctx, int64_t nsteps, double dt, double ktemp, uint64_t seed, int64_t first_step,
+                    int64_t virial_every, double *out)
+{
+    API_BEGIN
+    if (ctx->dom.on) throw HipError("md_run_brownian: not available on a slab-decomposition handle");
+    if (nsteps < 0 || nsteps > 0x3ffffff0) throw HipError("md_run_brownian: bad nsteps");
+    if (!(dt > 0.0) || !(ktemp > 0.0)) throw HipError("md_run_brownian: need dt > 0 and kT > 0");
+    if (virial_every < 1) virial_every = 10;
+    hipStream_t st = ctx->stream;
+    ctx->brown_acc.ensure(2);
+    HIPCHK(hipMemsetAsync(ctx->brown_acc.p, 0, 2 * sizeof(double), st));
+    const double sigma = std::sqrt(2.0 * dt), dt_over_kt = dt / ktemp;
+    ctx->list_valid = false; // (rows without inner pruning for this loop; positions may have been uploaded)
+    int64_t s = 0;
+    while (s < nsteps) {
+        if (!ctx->list_valid) rebuild(ctx);
+        int64_t chunk_end = std::min<int64_t>(nsteps, s + 32);
+        for (int64_t t = s; t < chunk_end; ++t) {
+            int64_t g = first_step + t;
+            bool sample = (g % virial_every) == 0;
+            bool want = sample || t == nsteps - 1;
+            launch_force(ctx, want, false, 0.0, (int)t);
+            if (want)
+                k_brownian_sums<<<1, 1024, 0, st>>>(ctx->nblk, ctx->partials.p, sample ? 1 : 0, ctx->brown_acc.p, ctx->scal.p,
+                                                    (int)t);
+            DevState sd = ctx->dev(ctx->cur);
+            if (ctx->dim == 3)
+                k_brownian_move<3><<<ctx->nblk, MD_BLOCK, 0, st>>>((int)ctx->n, sd, dt_over_kt, sigma, seed, g,
+                                                                   0.5 * ctx->skin, ctx->scal.p, (int)t);
+            else
+                k_brownian_move<2><<<ctx->nblk, MD_BLOCK, 0, st>>>((int)ctx->n, sd, dt_over_kt, sigma, seed, g,
+                                                                   0.5 * ctx->skin, ctx->scal.p, (int)t);
+        }
+        HIPCHK(hipGetLastError());
+        Scalars h = read_scalars(ctx);
+        if (h.first_viol <= chunk_end) {
+            // the move of step first_viol-1 took some particle skin/2 from its build position: rebuild before the
+            // next force evaluation (everything enqueued after that move skipped itself)
+            s = h.first_viol;
+            ctx->list_valid = false;
+            if (s < nsteps) ctx->st_viol++;
+        } else {
+            s = chunk_end;
+        }
+    }
+    k_reset_viol<<<1, 1, 0, st>>>(ctx->scal.p);
+    Scalars h = read_scalars(ctx);
+    double acc[2];
+    HIPCHK(hipMemcpyAsync(acc, ctx->brown_acc.p, sizeof acc, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (out) {
+        out[0] = h.U;
+        out[1] = h.W;
+        out[2] = acc[0];
+        out[3] = acc[1];
+    }
+    ctx->st_steps += nsteps;
     API_END
 }
 

@@ -141,6 +141,13 @@ class MDDevice:
                                            C.byref(en), C.byref(fr)))
         return dict(steps=st.value, converged=bool(cv.value), energy=en.value, f_rms=fr.value)
 
+    def run_brownian(self, nsteps, dt, ktemp, seed, first_step=0, virial_every=10):
+        """The Brownian step loop (src/simulation.jl:181-308); returns dict(U, W, virial_sum, virial_count)."""
+        out = np.zeros(4)
+        self._chk(self._L.md_run_brownian(self._h, int(nsteps), float(dt), float(ktemp), int(seed), int(first_step),
+                                          int(virial_every), _dp(out)))
+        return dict(U=out[0], W=out[1], virial_sum=out[2], virial_count=out[3])
+
     def kinetic(self):
         k = C.c_double()
         self._chk(self._L.md_kinetic(self._h, C.byref(k)))

@@ -35,8 +35,7 @@ def _configure_device(state, params):
 def run_simulation(state, params, ensemble, total_steps, frequency, pathname, traj_name="trajectory.xyz",
                    thermo_name="thermo.txt", compress=False, log_times=False, write_trajectory=True):
     """Python spelling of run_simulation! (mutates `state`, returns None)."""
-    if isinstance(ensemble, Brownian):
-        raise NotImplementedError("Brownian dynamics is out of scope (broken in the reference, SURVEY.md D9)")
+    brownian = isinstance(ensemble, Brownian)
     os.makedirs(pathname, exist_ok=True)
     trajectory_file, thermo_file = _io.open_files(pathname, traj_name, thermo_name)
     with open(thermo_file, "a") as io:
@@ -47,17 +46,26 @@ def run_simulation(state, params, ensemble, total_steps, frequency, pathname, tr
     n = params.n_particles
     pot = params.potential
     volume = compute_box_volume(state.unitcell)
-    if state.velocities is None or len(state.velocities) != n:
+    if not brownian and (state.velocities is None or len(state.velocities) != n):
         raise ValueError("state.velocities must be set before run_simulation (README.md:39-41)")
     # the host-side state is the truth at entry, exactly as in the reference
-    dev.upload(x=state.system.positions, v=state.velocities, f=state.system.energy_and_forces.forces,
-               images=state.images, diameters=state.diameters)
+    dev.upload(x=state.system.positions, v=None if brownian else state.velocities,
+               f=state.system.energy_and_forces.forces, images=state.images, diameters=state.diameters)
+    # Brownian method (src/simulation.jl:181-308): the device's noise stream is keyed by one draw of state.rng;
+    # the virial is sampled every 10th step and averaged at the output steps (:253-266)
+    brown_seed = int(state.rng.integers(1 << 63)) if brownian else 0
+    vir_acc = [0.0, 0.0]
 
     nvt = isinstance(ensemble, NVT)
     ens_kind = _lib.MD_NVT if nvt else _lib.MD_NVE
     tau = ensemble.tau if nvt else 0.0
 
     def segment(first_step, nsteps):
+        if brownian:
+            r = dev.run_brownian(nsteps, params.dt, ensemble.ktemp, brown_seed, first_step=first_step, virial_every=10)
+            vir_acc[0] += r["virial_sum"]
+            vir_acc[1] += r["virial_count"]
+            return r["U"], r["W"], 0.0
         kt = r1 = r2 = None
         if nvt:
             # ensemble_step! receives step+1 (src/simulation.jl:108)
@@ -85,10 +93,16 @@ def run_simulation(state, params, ensemble, total_steps, frequency, pathname, tr
         step = last + 1
         frame = None
         if last % frequency == 0:
-            temperature = 2.0 * K / state.nf
-            total_energy = (U + pot.energy_lrc(n, volume)) / n          # src/simulation.jl:433-437
-            pressure = W / (dim * volume) + params.rho * temperature    # :441-442
-            pressure += pot.pressure_lrc(n, volume)                     # :444
+            if brownian:
+                temperature = ensemble.ktemp                            # src/simulation.jl:259-266
+                total_energy = U / n
+                pressure = vir_acc[0] / (dim * max(vir_acc[1], 1.0) * volume) + params.rho * ensemble.ktemp
+                vir_acc[0] = vir_acc[1] = 0.0
+            else:
+                temperature = 2.0 * K / state.nf
+                total_energy = (U + pot.energy_lrc(n, volume)) / n      # src/simulation.jl:433-437
+                pressure = W / (dim * volume) + params.rho * temperature    # :441-442
+                pressure += pot.pressure_lrc(n, volume)                 # :444
             with open(thermo_file, "a") as io:
                 io.write("%d %.6f %.6f %.6f\n" % (last, total_energy, temperature, pressure))
             state.system.energy_and_forces.energy = U
@@ -107,7 +121,8 @@ def run_simulation(state, params, ensemble, total_steps, frequency, pathname, tr
     x, v, f, img = dev.download()
     state.system.positions = x
     state.system.xpositions = x
-    state.velocities = v
+    if not brownian:
+        state.velocities = v
     state.images = img
     state.system.energy_and_forces.forces = f
     # finalize_simulation!: src/simulation.jl:11-36

@@ -70,8 +70,10 @@ class NVT(Ensemble):
 
 
 class Brownian(Ensemble):
-    """src/types.jl:46-49.  The reference's Brownian path is broken (state.boxl / wrap_to_box!
-    do not exist: src/simulation.jl:210,273; src/integrate.jl:76) and is out of scope here."""
+    """src/types.jl:46-49.  The reference's Brownian method is broken (state.boxl / wrap_to_box! do not exist:
+    src/simulation.jl:210,273; src/integrate.jl:76; one RNG shared across threads).  run_simulation runs its
+    restatement on the device (md_run_brownian): x += f dt/kT + sqrt(2 dt) * uniform(+-sqrt 3) noise from a
+    counter-based Philox stream."""
 
     def __init__(self, ktemp):
         self.ktemp = float(ktemp)

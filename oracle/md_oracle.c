@@ -691,6 +691,80 @@ int oracle_fire_minimize(int dim, int n, double *x, int32_t *img, double *f, con
     return steps;
 }
 
+/* Philox4x32-10 (Salmon et al., SC'11), the counter-based generator the device's Brownian noise uses. */
+static void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4])
+{
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0;
+        c1 = n1;
+        c2 = n2;
+        c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0;
+    out[1] = c1;
+    out[2] = c2;
+    out[3] = c3;
+}
+
+void oracle_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t *out)
+{
+    philox4x32_10(c0, c1, c2, c3, k0, k1, out);
+}
+
+/* The Brownian step loop, src/simulation.jl:181-308 with integrate_brownian! src/integrate.jl:66-82 (broken in
+ * the reference, SURVEY.md D9: undefined names, one RNG and one noise buffer shared across threads).  Per step
+ * s = 0..nsteps-1: forces at x (:233-240); x_i += f_i*dt/kT + noise_i*sigma, sigma = sqrt(2 dt) (:213),
+ * noise = (2u-1)*sqrt(3) per component (src/integrate.jl:55-59), then wrap + images; the virial is sampled on
+ * steps with step % virial_every == 0 (:253-256, every 10th).  u: Philox4x32-10, key = seed, counter =
+ * (particle index, first_step + s): u_c = (word_c + 1/2) / 2^32.
+ * out = {U, W of the last step's force evaluation, virial sum, samples}. */
+int oracle_run_brownian(int dim, int n, double *x, int32_t *img, double *f, const double *diam, const double *L,
+                        double cutoff, const oracle_pot *pot, double dt, double ktemp, uint64_t seed,
+                        int64_t first_step, int nsteps, int virial_every, int use_cells, int nthreads, double *out)
+{
+    double invL[3];
+    for (int c = 0; c < dim; ++c) invL[c] = 1.0 / L[c];
+    const double sigma = sqrt(2.0 * dt), dt_over_kt = dt / ktemp;
+    double U = 0.0, W = 0.0, vsum = 0.0, vcnt = 0.0;
+    for (int s = 0; s < nsteps; ++s) {
+        int64_t g = first_step + s;
+        if (use_cells)
+            oracle_forces_cells(dim, n, x, L, cutoff, pot, diam, f, &U, &W, nthreads);
+        else
+            oracle_forces_brute(dim, n, x, L, cutoff, pot, diam, f, &U, &W, NULL, 0);
+        if (g % virial_every == 0) {
+            vsum += W;
+            vcnt += 1.0;
+        }
+        for (int i = 0; i < n; ++i) {
+            uint32_t w[4];
+            philox4x32_10((uint32_t)i, (uint32_t)g, (uint32_t)((uint64_t)g >> 32), 0u, (uint32_t)seed,
+                          (uint32_t)(seed >> 32), w);
+            for (int c = 0; c < dim; ++c) {
+                size_t k = (size_t)i * dim + c;
+                double u = ((double)w[c] + 0.5) * 2.3283064365386963e-10;
+                double noise = (2.0 * u - 1.0) * 1.7320508075688772;
+                x[k] = x[k] + (f[k] * dt_over_kt) + (noise * sigma);
+                x[k] = wrap1(x[k], &img[k], L[c], invL[c]);
+            }
+        }
+    }
+    if (out) {
+        out[0] = U;
+        out[1] = W;
+        out[2] = vsum;
+        out[3] = vcnt;
+    }
+    return 0;
+}
+
 int oracle_max_threads(void)
 {
 #ifdef _OPENMP

@@ -201,3 +201,25 @@ def fire_minimize(x, img, diam, box, cutoff, pot, max_steps=10000, tol=1e-6, dt_
                C.c_double(alpha0), C.c_double(f_inc), C.c_double(f_dec), C.c_int(nmin), C.c_int(1 if use_cells else 0),
                C.c_int(nthreads), C.byref(conv), C.byref(en), C.byref(frms))
     return dict(x=x, img=img, f=f, steps=int(steps), converged=bool(conv.value), energy=en.value, f_rms=frms.value)
+
+
+def philox(c, k):
+    """Philox4x32-10 block: counter c = 4 words, key k = 2 words -> 4 words."""
+    out = (C.c_uint32 * 4)()
+    lib().oracle_philox(*(C.c_uint32(int(v)) for v in c), *(C.c_uint32(int(v)) for v in k), out)
+    return [int(v) for v in out]
+
+
+def run_brownian(x, img, diam, box, cutoff, pot, dt, ktemp, seed, nsteps, first_step=0, virial_every=10, use_cells=True,
+                 nthreads=2):
+    """The Brownian step loop (src/simulation.jl:181-308) on copies; dict(x, img, f, U, W, virial_sum, virial_count)."""
+    x = _f64(x).copy()
+    img = np.ascontiguousarray(img, dtype=np.int32).copy()
+    n, d = x.shape
+    f = np.zeros_like(x)
+    out = np.zeros(4)
+    lib().oracle_run_brownian(C.c_int(d), C.c_int(n), _d(x), _i(img), _d(f), _d(_f64(diam)), _d(_f64(box)),
+                              C.c_double(cutoff), C.byref(pot), C.c_double(dt), C.c_double(ktemp), C.c_uint64(seed),
+                              C.c_int64(first_step), C.c_int(nsteps), C.c_int(virial_every),
+                              C.c_int(1 if use_cells else 0), C.c_int(nthreads), _d(out))
+    return dict(x=x, img=img, f=f, U=out[0], W=out[1], virial_sum=out[2], virial_count=out[3])
