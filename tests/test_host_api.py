@@ -164,11 +164,11 @@ def test_xyz_roundtrip_and_lammps_dump(tmp_path):
     assert first[0] == 1 and first[6] == pytest.approx(x[0, 0] + 7.0 * img[0, 0], abs=1e-5)
 
 
-def test_run_simulation_rejects_out_of_scope():
+def test_unknown_minimiser_is_rejected():
     st = type("S", (), {})()
     p = md.Parameters(0.9, 10, 0.001, md.LennardJones())
-    with pytest.raises(NotImplementedError, match="Brownian"):
-        md.run_simulation(st, p, md.Brownian(1.0), 10, 1, "/tmp/x")
+    with pytest.raises(ValueError, match="Unknown minimization method"):      # src/minimize.jl:179
+        md.minimize(st, p, "/tmp/x", 3, method="LBFGS")
 
 
 def test_log_times_schedule(tmp_path):
