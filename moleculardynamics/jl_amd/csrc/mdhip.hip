@@ -1508,6 +1508,7 @@ int md_fire_minimize(md_ctx *ctx, int64_t max_steps, double tol, double dt_initi
         k_reset_viol<<<1, 1, 0, st>>>(ctx->scal.p);
     }
     if (md_upload(ctx, nullptr, vsave.data(), nullptr, nullptr, nullptr) != 0) return 1;
+    ctx->list_valid = false; // (this loop kept none of the step loop's bookkeeping: the next md_run starts from a build)
     if (steps) *steps = s;
     if (converged) *converged = conv ? 1 : 0;
     if (energy) *energy = hf.energy;
@@ -1573,6 +1574,7 @@ int md_run_brownian(md_ctx *ctx, int64_t nsteps, double dt, double ktemp, uint64
         out[2] = acc[0];
         out[3] = acc[1];
     }
+    ctx->list_valid = false; // (see md_fire_minimize)
     ctx->st_steps += nsteps;
     API_END
 }
