@@ -361,6 +361,9 @@ void configure_potential(md_ctx *c)
     c->pp.c48 = 48.0 * c->pp.p[0];
     c->pp.c24 = 24.0 * c->pp.p[0];
     c->pp.c4 = 4.0 * c->pp.p[0];
+    double s6 = c->pp.sig2u * c->pp.sig2u * c->pp.sig2u;
+    c->pp.ljA = c->pp.c48 * s6 * s6;
+    c->pp.ljB = c->pp.c24 * s6;
 }
 
 void ensure_capacity(md_ctx *c, int64_t need_next)
