@@ -563,6 +563,23 @@ void rebuild_t(md_ctx *c)
     c->virtual_ghosts = c->use_tiles && c->cap < (1ll << 26);
     if (c->virtual_ghosts && nghost > 0)
         k_halo_virtualize<<<c->nblk, MD_BLOCK, 0, st>>>(n, c->halo.p, c->hcap, c->halo_count.p, c->gowner.p, c->gcode.p);
+    if (getenv("MDHIP_ROWSTATS")) {
+        std::vector<int32_t> nn((size_t)n), nm((size_t)c->ntiles);
+        HIPCHK(hipMemcpyAsync(nn.data(), c->nneigh.p, sizeof(int32_t) * n, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(nm.data(), c->nmax_tile.p, sizeof(int32_t) * c->ntiles, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        double mean = 0, padded = 0, sorted_p = 0, p8 = 0, s8 = 0;
+        for (int i = 0; i < n; ++i) mean += nn[i];
+        for (int w = 0; w < (n + 63) / 64; ++w) { padded += nm[w]; p8 += (nm[w] + 7) & ~7; }
+        for (int t0 = 0; t0 + 256 <= n; t0 += 256) {
+            std::vector<int> v(nn.begin() + t0, nn.begin() + t0 + 256);
+            std::sort(v.begin(), v.end());
+            for (int w = 0; w < 4; ++w) { int mx = (v[64 * w + 63] + 3) & ~3; sorted_p += mx; s8 += (mx + 7) & ~7; }
+        }
+        int nw = (n + 63) / 64;
+        fprintf(stderr, "[mdhip] rows: mean %.2f  wave-max(4) %.2f  wave-max(8) %.2f  sorted-within-tile(4) %.2f  (8) %.2f\n",
+                mean / n, padded / nw, p8 / nw, sorted_p / nw, s8 / nw);
+    }
     c->list_valid = true;
     c->steps_since_build = 0;
     c->st_rebuilds++;
