@@ -29,6 +29,7 @@ HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 STEP_BYTES = {"nve": 332.0, "nvt": 380.0}   # algorithmic bytes per particle-step
 # the fused force kernel reads x (24 B) and v (24 B) and writes f (24 B) and v (24 B) per owned
 # particle (uniform diameter; +8 B sigma otherwise): DESIGN.md "kernels"
+KICKDRIFT_BYTES = 160   # R pos 32 + v 24 + f 24 + x1 24, W pos 32 + v 24
 FORCE_KERNEL_BYTES = 96.0
 
 
@@ -215,7 +216,10 @@ def main():
     run(a.equil)           # melt the lattice so the timed region sees a liquid, untimed
     run(a.warmup)
     st0 = dev.stats()
-    dev.profile(True)
+    # kernel durations: HIP events on the handle's stream around every 7th force and kick-drift launch of the
+    # timed region (every launch would cost ~8 % of the throughput being measured; 7 is coprime to the prune
+    # cadence, so ordinary and prune steps are sampled in proportion)
+    dev.profile(0 if os.environ.get("MDHIP_BENCH_NOPROF", "0") == "1" else 7)
     barrier()
     t0 = time.perf_counter()
     uwk = run(a.steps, thermo=True)
@@ -280,6 +284,14 @@ def main():
             "kernel_launches": launches,
             "bytes_per_launch": FORCE_KERNEL_BYTES * a.n,
         },
+        # the stream kernel of the step (pending rescale + half-kick + drift + displacement check): HBM-bound
+        "kickdrift_roofline": {
+            "bound": "hbm", "bytes_per_launch": KICKDRIFT_BYTES * a.n,
+            "kernel_ms": (st1["kickdrift_ms"] / max(1, st1["kickdrift_launches"])),
+            "achieved": (KICKDRIFT_BYTES * a.n) / max(1e-12, st1["kickdrift_ms"] / max(1, st1["kickdrift_launches"]) * 1e-3) / 1e9,
+            "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": (KICKDRIFT_BYTES * a.n) / max(1e-12, st1["kickdrift_ms"] / max(1, st1["kickdrift_launches"]) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+        } if st1["kickdrift_launches"] > 0 else None,
         "step_roofline": {
             "algorithmic_bytes_per_particle_step": step_bytes,
             "achieved_GBps": value / world * step_bytes / 1e9,

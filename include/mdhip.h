@@ -149,7 +149,11 @@ typedef struct {
     int64_t max_halo;       /* largest per-tile halo (LDS-staged neighbours) of the last build */
     int64_t tiled;          /* 1 if the LDS-tiled force kernel is in use, 0 if the global-gather one */
     int64_t prunes;         /* row prunes (inner-list refreshes) since create */
+    int64_t kickdrift_launches; /* kick-drift kernel launches timed since md_profile(ctx,1) */
+    double kickdrift_ms;        /* their summed duration */
 } md_stats;
+/* enable = 0: off; 1: HIP events around every force and kick-drift launch; k > 1: around every k-th launch of each
+ * (an event record costs a few microseconds of device time: sampling keeps a timed run honest) */
 int md_profile(md_ctx *ctx, int enable);
 int md_get_stats(md_ctx *ctx, md_stats *out);
 

@@ -188,10 +188,16 @@ struct md_ctx {
     // stats / profiling
     int64_t st_steps = 0, st_rebuilds = 0, st_viol = 0;
     bool prof = false;
+    int prof_stride = 1;          // time every prof_stride-th launch of each kind (event records cost ~4 us each)
+    int64_t prof_seen[2] = {0, 0};
+    bool prof_open = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
     size_t prof_used = 0;
     double prof_ms_acc = 0.0;
     int64_t prof_launch_acc = 0;
+    std::vector<int> prof_tag;          // 0: force kernel, 1: kick-drift kernel
+    double prof_kd_ms_acc = 0.0;
+    int64_t prof_kd_launch_acc = 0;
 
     std::string err;
 
@@ -604,21 +610,26 @@ void rebuild(md_ctx *c)
     HIPCHK(hipGetLastError());
 }
 
-void prof_begin(md_ctx *c)
+void prof_begin(md_ctx *c, int tag = 0)
 {
     if (!c->prof) return;
+    c->prof_open = (c->prof_seen[tag]++ % c->prof_stride) == 0;
+    if (!c->prof_open) return;
     if (c->prof_used >= c->prof_ev.size()) {
-        if (c->prof_ev.size() >= 4096) return;
+        if (c->prof_ev.size() >= 8192) return;
         hipEvent_t a, b;
         HIPCHK(hipEventCreate(&a));
         HIPCHK(hipEventCreate(&b));
         c->prof_ev.emplace_back(a, b);
+        c->prof_tag.push_back(0);
     }
+    c->prof_tag[c->prof_used] = tag;
     HIPCHK(hipEventRecord(c->prof_ev[c->prof_used].first, c->stream));
 }
 void prof_end(md_ctx *c)
 {
-    if (!c->prof) return;
+    if (!c->prof || !c->prof_open) return;
+    c->prof_open = false;
     if (c->prof_used >= c->prof_ev.size()) return;
     HIPCHK(hipEventRecord(c->prof_ev[c->prof_used].second, c->stream));
     c->prof_used++;
@@ -630,8 +641,13 @@ void prof_collect(md_ctx *c)
     for (size_t i = 0; i < c->prof_used; ++i) {
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, c->prof_ev[i].first, c->prof_ev[i].second));
-        c->prof_ms_acc += ms;
-        c->prof_launch_acc++;
+        if (c->prof_tag[i] == 1) {
+            c->prof_kd_ms_acc += ms;
+            c->prof_kd_launch_acc++;
+        } else {
+            c->prof_ms_acc += ms;
+            c->prof_launch_acc++;
+        }
     }
     c->prof_used = 0;
 }
@@ -795,6 +811,7 @@ void launch_kickdrift(md_ctx *c, bool nvt, double dt, bool check, int step)
     double skin_half = check ? 0.5 * c->skin : INFINITY;
     double inner_half = check ? (c->inner_valid ? 0.5 * c->inner_skin : 0.5 * c->skin) : INFINITY;
     int use_d1 = c->inner_valid ? 1 : 0;
+    prof_begin(c, 1);
     if (c->dim == 3) {
         if (nvt)
             k_kickdrift<3, true><<<nb, MD_BLOCK, 0, c->stream>>>(n, s, dt, skin_half, inner_half, use_d1, c->scal.p, step);
@@ -806,6 +823,7 @@ void launch_kickdrift(md_ctx *c, bool nvt, double dt, bool check, int step)
         else
             k_kickdrift<2, false><<<nb, MD_BLOCK, 0, c->stream>>>(n, s, dt, skin_half, inner_half, use_d1, c->scal.p, step);
     }
+    prof_end(c);
 }
 
 void launch_ghost_update(md_ctx *c, int step)
@@ -1632,9 +1650,13 @@ int md_profile(md_ctx *ctx, int enable)
     API_BEGIN
     prof_collect(ctx);
     ctx->prof = enable != 0;
+    ctx->prof_stride = enable > 1 ? enable : 1;
+    ctx->prof_seen[0] = ctx->prof_seen[1] = 0;
     if (enable) {
         ctx->prof_ms_acc = 0.0;
         ctx->prof_launch_acc = 0;
+        ctx->prof_kd_ms_acc = 0.0;
+        ctx->prof_kd_launch_acc = 0;
     }
     API_END
 }
@@ -1663,6 +1685,8 @@ int md_get_stats(md_ctx *ctx, md_stats *out)
     out->tiled = ctx->use_tiles ? 1 : 0;
     out->force_launches = ctx->prof_launch_acc;
     out->force_ms = ctx->prof_ms_acc;
+    out->kickdrift_launches = ctx->prof_kd_launch_acc;
+    out->kickdrift_ms = ctx->prof_kd_ms_acc;
     API_END
 }
 

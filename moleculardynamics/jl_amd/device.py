@@ -158,7 +158,8 @@ class MDDevice:
 
     # -- instrumentation ------------------------------------------------------------------
     def profile(self, enable=True):
-        self._chk(self._L.md_profile(self._h, 1 if enable else 0))
+        """True/1: time every force and kick-drift launch; k > 1: every k-th; False/0: off."""
+        self._chk(self._L.md_profile(self._h, int(enable)))
 
     def stats(self):
         s = MdStats()

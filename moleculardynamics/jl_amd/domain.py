@@ -236,7 +236,7 @@ class DomainDevice:
         self._chk(self._L.md_dom_set_uniform(self._h, 1 if uniform else 0, float(sigma)))
 
     def profile(self, enable=True):
-        self._chk(self._L.md_profile(self._h, 1 if enable else 0))
+        self._chk(self._L.md_profile(self._h, int(enable)))
 
     def stats(self):
         s = _lib.MdStats()
