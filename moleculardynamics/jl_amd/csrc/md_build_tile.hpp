@@ -62,14 +62,16 @@ __device__ __forceinline__ int block_excl_scan(int v, int *lds, int *total)
 // host falls back to the two-kernel build.
 #define MD_HALF_CELLS 14
 
+typedef float md_f2 __attribute__((ext_vector_type(2)));
+
 template <int D>
 __device__ __forceinline__ int tile_sweep_mark(float xi, float yi, float zi, const uint16_t *ctab_row, float rl2f,
                                                int self_q, int n0, int n1, const float *px, const float *py,
-                                               const float *pz, const int *coff, unsigned char *ref,
-                                               unsigned char *trash, unsigned long long *mask, int *qstart,
-                                               bool *too_big)
+                                               const float *pz, const int *coff, unsigned long long *refmask,
+                                               unsigned long long *mask, int *qstart, bool *too_big)
 {
     int cnt = 0;
+    const md_f2 xi2 = {xi, xi}, yi2 = {yi, yi}, zi2 = {zi, zi};
 #pragma unroll
     for (int ci = 0; ci < MD_HALF_CELLS; ++ci) {
         mask[ci] = 0ull;
@@ -85,33 +87,31 @@ __device__ __forceinline__ int tile_sweep_mark(float xi, float yi, float zi, con
         }
         qstart[ci] = qs;
         unsigned long long mk = 0ull;
+        // four candidates per iteration, two per packed fp32 instruction (v_pk_add/mul/fma_f32); their four hit
+        // bits are assembled as a nibble and shifted into the cell's mask once
         for (int q0 = qs; q0 < qe; q0 += 4) {
             float4 x4 = *(const float4 *)(px + q0);
             float4 y4 = *(const float4 *)(py + q0);
-            float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if constexpr (D == 3) z4 = *(const float4 *)(pz + q0);
-            const float xq[4] = {x4.x, x4.y, x4.z, x4.w};
-            const float yq[4] = {y4.x, y4.y, y4.z, y4.w};
-            const float zq[4] = {z4.x, z4.y, z4.z, z4.w};
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                int q = q0 + b;
-                float ddx = xq[b] - xi;
-                float ddy = yq[b] - yi;
-                float d2 = ddx * ddx;
-                d2 = __builtin_fmaf(ddy, ddy, d2);
-                if constexpr (D == 3) {
-                    float ddz = zq[b] - zi;
-                    d2 = __builtin_fmaf(ddz, ddz, d2);
-                }
-                bool hit = (d2 <= rl2f) & (q != self_q); // pad entries are 1e30 away
-                // misses write a per-lane trash byte (one shared trash byte would make ~55 lanes hit
-                // one LDS address per instruction)
-                unsigned char *dst = hit ? (ref + q) : trash;
-                *dst = 1;
-                mk |= (unsigned long long)(hit ? 1u : 0u) << (q - qs);
+            md_f2 dxa = md_f2{x4.x, x4.y} - xi2, dxb = md_f2{x4.z, x4.w} - xi2;
+            md_f2 dya = md_f2{y4.x, y4.y} - yi2, dyb = md_f2{y4.z, y4.w} - yi2;
+            md_f2 da = dxa * dxa, db = dxb * dxb;
+            da = __builtin_elementwise_fma(dya, dya, da);
+            db = __builtin_elementwise_fma(dyb, dyb, db);
+            if constexpr (D == 3) {
+                float4 z4 = *(const float4 *)(pz + q0);
+                md_f2 dza = md_f2{z4.x, z4.y} - zi2, dzb = md_f2{z4.z, z4.w} - zi2;
+                da = __builtin_elementwise_fma(dza, dza, da);
+                db = __builtin_elementwise_fma(dzb, dzb, db);
             }
+            // (pad entries are 1e30 away: they never hit)
+            unsigned nib = (da.x <= rl2f ? 1u : 0u) | (da.y <= rl2f ? 2u : 0u) | (db.x <= rl2f ? 4u : 0u) |
+                           (db.y <= rl2f ? 8u : 0u);
+            mk |= (unsigned long long)nib << (q0 - qs);
         }
+        // the particle itself sits in its own cell's range
+        if (self_q >= qs && self_q < qe) mk &= ~(1ull << (self_q - qs));
+        // which staged particles the tile references at all: one 64-bit OR per (particle, cell)
+        if (mk) atomicOr(&refmask[lo], mk);
         mask[ci] = mk;
         cnt += __popcll(mk);
     }
@@ -131,6 +131,8 @@ __device__ __forceinline__ int tile_sweep_emit(const unsigned long long *mask, c
             int b = __ffsll((long long)mk) - 1;
             mk &= mk - 1ull;
             unsigned v = (unsigned)newidx[qs + b] * (unsigned)rs;
+            // (entry-by-entry 2-byte stores: collecting four entries into one 8-byte store made this sweep 50 %
+            // slower -- the bookkeeping in the divergent bit walk costs more than the stores)
             if (cnt < maxn) rowbase[row_off(cnt, lane)] = (uint16_t)v;
             ++cnt;
         }
@@ -152,7 +154,7 @@ __global__ void __launch_bounds__(MD_BT_THREADS)
     MD_STAMP(0);
     __shared__ __attribute__((aligned(16))) float px[MD_SCAP], py[MD_SCAP], pz[MD_SCAP];
     __shared__ uint16_t newidx[MD_SCAP];
-    __shared__ unsigned char ref[MD_SCAP];
+    __shared__ unsigned long long refmask[MD_NCMAX]; // per unique cell: which of its (<= 64) staged particles some row references
     __shared__ int ccell[MD_NCMAX], ucell[MD_NCMAX], coff[MD_NCMAX + 2];
     __shared__ unsigned char ccnt[MD_NCMAX]; // real (unpadded) population of unique cell u (<= 64)
     __shared__ int ncand[MD_NCMAX];           // neighbour cell of candidate t = (owned cell ci, offset nb), unsorted
@@ -161,7 +163,6 @@ __global__ void __launch_bounds__(MD_BT_THREADS)
     __shared__ int sh_misc[4];
     __shared__ int sh_scan[16];
     __shared__ int sh_ne[MD_NEMAX];
-    __shared__ unsigned char sh_trash[4 * MD_BT_THREADS];
 
     const int tile = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -184,7 +185,7 @@ __global__ void __launch_bounds__(MD_BT_THREADS)
     const int last_active = min(n - 1, tile * MD_TILE + MD_TILE - 1) - tile * MD_TILE;
     if (tid == last_active) sh_misc[1] = mycell;
     if (tid == 0) sh_misc[2] = 0;
-    for (int i = tid; i < MD_SCAP; i += MD_BT_THREADS) ref[i] = 0;
+    for (int i = tid; i < MD_NCMAX; i += MD_BT_THREADS) refmask[i] = 0ull;
     __syncthreads();
     const int c_first = sh_misc[0], c_last = sh_misc[1];
     const int R = c_last - c_first + 1; // index slots spanned (includes unused brick slots)
@@ -342,8 +343,8 @@ __global__ void __launch_bounds__(MD_BT_THREADS)
     int cnt = 0;
     bool too_big = false;
     if (active)
-        cnt = tile_sweep_mark<D>(xi, yi, zi, ctab + myci * NNB, rl2f, self_q, n0, n1, px, py, pz, coff, ref,
-                                 sh_trash + 4 * tid, hmask, qstart, &too_big);
+        cnt = tile_sweep_mark<D>(xi, yi, zi, ctab + myci * NNB, rl2f, self_q, n0, n1, px, py, pz, coff, refmask, hmask,
+                                 qstart, &too_big);
     else {
 #pragma unroll
         for (int ci = 0; ci < MD_HALF_CELLS; ++ci) {
@@ -358,25 +359,24 @@ __global__ void __launch_bounds__(MD_BT_THREADS)
     // 4. compact the referenced particles into the halo
     int H;
     {
-        const int per = MD_SCAP / MD_BT_THREADS;
+        // by unique cell (halo order = staged order: cell by cell, particles of a cell in slot order)
+        const int per = (MD_NCMAX + MD_BT_THREADS - 1) / MD_BT_THREADS;
         int c = 0;
-        for (int q = 0; q < per; ++q) c += (tid * per + q < S) ? ref[tid * per + q] : 0;
+        for (int q = 0; q < per; ++q) {
+            int u = tid * per + q;
+            if (u < nu) c += __popcll(refmask[u]);
+        }
         int run = block_excl_scan(c, sh_scan, &H);
         for (int q = 0; q < per; ++q) {
-            int i = tid * per + q;
-            if (i < S && ref[i]) {
-                newidx[i] = (uint16_t)run;
-                if (run < hcap) {
-                    int lo = 0, hi = nu;
-                    while (hi - lo > 1) {
-                        int mid = (lo + hi) >> 1;
-                        if (coff[mid] <= i)
-                            lo = mid;
-                        else
-                            hi = mid;
-                    }
-                    halo[(size_t)tile * hcap + run] = (uint32_t)(cell_start[ucell[lo]] + (i - coff[lo]));
-                }
+            int u = tid * per + q;
+            if (u >= nu) continue;
+            unsigned long long mk = refmask[u];
+            const int base = coff[u], src0 = cell_start[ucell[u]];
+            while (mk) {
+                int bit = __ffsll((long long)mk) - 1;
+                mk &= mk - 1ull;
+                newidx[base + bit] = (uint16_t)run;
+                if (run < hcap) halo[(size_t)tile * hcap + run] = (uint32_t)(src0 + bit);
                 ++run;
             }
         }
