@@ -927,7 +927,7 @@ __global__ void __launch_bounds__(MD_TILE)
             if constexpr (D == 3) zj[q] = rec[2];
             if constexpr (!UNIFORM) wj[q] = rec[3];
         }
-        if constexpr (POT == POT_LJ && UNIFORM && !WANT_UW && !PRUNE && D == 3) {
+        if constexpr (POT == POT_LJ && UNIFORM && !WANT_UW && D == 3) {
             // LJ, one diameter, no energies: candidates in pairs share one reciprocal,
             //   1/a = b * 1/(ab), 1/b = a * 1/(ab)   (masked d^2 = 2^511: the product stays finite),
             // and the force uses the sigma-folded polynomial f/r = z^4 (A z^3 - B), z = 1/r^2.
@@ -940,6 +940,16 @@ __global__ void __launch_bounds__(MD_TILE)
                 double d2 = dxq[q] * dxq[q];
                 d2 = __builtin_fma(dyq[q], dyq[q], d2);
                 d2 = __builtin_fma(dzq[q], dzq[q], d2);
+                if constexpr (PRUNE) {
+                    if (d2 <= rin2) { // (padding entries are 1e100 away: they never survive)
+                        acc |= (unsigned long long)o[q] << (16 * (cin & 3));
+                        ++cin;
+                        if ((cin & 3) == 0) {
+                            rin64[(size_t)((cin >> 2) - 1) * 64] = acc;
+                            acc = 0ull;
+                        }
+                    }
+                }
                 int hi = __double2hiint(d2);
                 hi = (d2 < pp.c2) ? hi : 0x5fe00000;
                 dm[q] = __hiloint2double(hi, __double2loint(d2));
