@@ -198,7 +198,8 @@ int md_dom_step_end(md_ctx *ctx, double dt, int want_uw, double *uwk);
 int md_dom_forces(md_ctx *ctx, double dt, int kick, int want_uw, double *uwk);
 /* velocity scale to apply in front of the next half-kick (bussi!'s rescale, src/thermostat.jl:43-45) */
 int md_dom_set_scale(md_ctx *ctx, double scale);
-int md_dom_counts(md_ctx *ctx, int64_t *out /* [6]: n_own, nsend_halo L,R, nrecv_halo L,R, n_ghost */);
+int md_dom_counts(md_ctx *ctx, int64_t *out /* [8]: n_own, nsend_halo L,R, nrecv_halo L,R, n_ghost, 1 if the tiled
+                                                  force kernel is in use, 1 if inner rows are active */);
 
 /* Asynchronous slab stepping -- none of these waits for the device.  The caller enqueues on ONE stream, per
  * step,   md_dom_step_a -> all-reduce(MIN) of *flag_dev + neighbour exchange of the step buffers ->

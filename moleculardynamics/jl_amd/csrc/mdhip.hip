@@ -2386,7 +2386,7 @@ int md_dom_set_scale(md_ctx *ctx, double scale)
     API_END
 }
 
-int md_dom_counts(md_ctx *ctx, int64_t *out /* n_own, nsend_halo L/R, nrecv_halo L/R, n_ghost */)
+int md_dom_counts(md_ctx *ctx, int64_t *out /* [8]: n_own, nsend_halo L/R, nrecv_halo L/R, n_ghost, tiled, pruning */)
 {
     API_BEGIN
     dom_require(ctx);
@@ -2396,6 +2396,8 @@ int md_dom_counts(md_ctx *ctx, int64_t *out /* n_own, nsend_halo L/R, nrecv_halo
     out[3] = ctx->dom.nrecv_halo[0];
     out[4] = ctx->dom.nrecv_halo[1];
     out[5] = ctx->nghost;
+    out[6] = ctx->use_tiles ? 1 : 0;
+    out[7] = ctx->prune_on ? 1 : 0;
     API_END
 }
 

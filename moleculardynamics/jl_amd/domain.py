@@ -163,8 +163,8 @@ class Exchanger:
 
     def allreduce(self, values, op="sum"):
         t = self.torch.tensor(values, dtype=self.torch.float64, device=self.coll_device)
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM if op == "sum" else self.dist.ReduceOp.MAX,
-                             group=self.group)
+        rop = {"sum": self.dist.ReduceOp.SUM, "max": self.dist.ReduceOp.MAX, "min": self.dist.ReduceOp.MIN}[op]
+        self.dist.all_reduce(t, op=rop, group=self.group)
         return t.tolist()
 
 
@@ -300,9 +300,10 @@ class DomainDevice:
         return X, V, F, IM
 
     def counts(self):
-        out = (C.c_int64 * 6)()
+        out = (C.c_int64 * 8)()
         self._chk(self._L.md_dom_counts(self._h, out))
-        return dict(n_own=out[0], nsend_halo=(out[1], out[2]), nrecv_halo=(out[3], out[4]), n_ghost=out[5])
+        return dict(n_own=out[0], nsend_halo=(out[1], out[2]), nrecv_halo=(out[3], out[4]), n_ghost=out[5],
+                    tiled=bool(out[6]), pruning=bool(out[7]))
 
     # -- exchange plumbing ----------------------------------------------------------------------
     def _exchange(self, nsend, rec):
@@ -376,6 +377,16 @@ class DomainDevice:
         self._bind_step_buffers(); lap()
         self.steps_since_build = 0
         self.builds += 1
+        if getattr(self, "_prune_req", False):
+            # inner rows need the tiled kernel on EVERY rank (the prune schedule is planned once for all): if some
+            # rank's build fell back, nobody prunes
+            ok = self.ex.allreduce([1.0 if self.counts()["pruning"] else 0.0], op="min")[0] > 0.0
+            if not ok:
+                self._chk(self._L.md_dom_enable_pruning(self._h, 0))
+                self._prune_req = False
+                self._pruning = False
+                self.build()
+                return
         if tm is not None and self.rank == 0:
             names = ("migrate_pack", "exchange", "migrate_unpack", "halo_pack", "exchange", "halo_unpack", "build", "bind")
             print("[dom build] " + " ".join(f"{n}={1e6 * (b - a):.0f}us" for n, a, b in zip(names, tm, tm[1:]))
