@@ -27,6 +27,9 @@ def main():
     nsteps = int(os.environ.get("DOM_STEPS", "60"))
     nvt = os.environ.get("DOM_NVT", "0") == "1"
     s = lj_system(n, kT=kT, permute=777)     # shuffled ids: ownership is by position, not by index
+    if os.environ.get("DOM_POLY", "0") == "1":
+        # per-particle diameters: the 32-byte LDS records and the diameter column of migrants / halo records
+        s["diam"] = np.random.default_rng(5).uniform(0.9, 1.1, n)
     LJ = [1.0, 1.0, 2.5]
     ex = Exchanger(device_index=0)
     rng = np.random.default_rng(99)
