@@ -204,7 +204,9 @@ int md_dom_counts(md_ctx *ctx, int64_t *out /* [8]: n_own, nsend_halo L,R, nrecv
 /* Asynchronous slab stepping -- none of these waits for the device.  The caller enqueues on ONE stream, per
  * step,   md_dom_step_a -> all-reduce(MIN) of *flag_dev + neighbour exchange of the step buffers ->
  *         md_dom_step_b -> all-reduce(SUM) of kuw_dev[3] -> md_dom_step_c
- * (the last two only for MD_NVT or on a step that reports U/W/K), a whole window of steps at a time, with
+ * (the all-reduce only for MD_NVT or on a step that reports U/W/K; md_dom_step_c only on such a reporting step
+ * and on the LAST step of a window -- when it is skipped, the next md_dom_step_a forms the Bussi scale from the
+ * reduced sums itself), a whole window of steps at a time, with
  * 0-based step numbers inside the window; ktemp/r1/r2 are indexed by them (same meaning as md_run's).  A
  * displacement violation on any rank at step m reaches every rank through the reduced flag before step m's
  * force evaluation: all later kernels of the window skip themselves on every rank (the single-GPU scheme of

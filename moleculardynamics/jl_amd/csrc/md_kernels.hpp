@@ -1072,9 +1072,20 @@ __global__ void __launch_bounds__(MD_TILE)
 // src/thermostat.jl:43-45).  Wrapping is deferred to the next list build; the displacement
 // since the last build is checked against (skin/2)^2 and the first violating step recorded.
 // ------------------------------------------------------------------------------------------
+// Where the pending Bussi scale comes from: sc->scale (written by k_finalize), or -- slab decomposition, where the
+// kinetic energy is all-reduced between the kernels -- recomputed by every thread from the reduced sums with the
+// arithmetic of k_finalize (src/thermostat.jl:36-40), which saves a one-thread kernel per step.
+struct BussiSrc {
+    const double *sums; // {sum v^2, ...} all-reduced, or nullptr: use sc->scale
+    const double *kt, *r1, *r2;
+    double nf, term1;
+    int idx; // the step whose thermostat draw applies
+};
+
 template <int D, bool SCALE>
 __global__ void __launch_bounds__(MD_BLOCK)
-    k_kickdrift(int n, DevState s, double dt, double skin_half, double inner_half, int use_d1, Scalars *sc, int step)
+    k_kickdrift(int n, DevState s, double dt, double skin_half, double inner_half, int use_d1, Scalars *sc, int step,
+                BussiSrc bs)
 {
     if (sc->first_viol < step) return;
     int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1088,7 +1099,19 @@ __global__ void __launch_bounds__(MD_BLOCK)
     double disp2 = 0.0;
     if (k < n) {
         double scale = 1.0;
-        if constexpr (SCALE) scale = sc->scale;
+        if constexpr (SCALE) {
+            if (bs.sums) {
+                double K = bs.sums[0] / 2.0;
+                double tc = 2.0 * K / bs.nf;
+                double rr1 = bs.r1[bs.idx], rr2 = bs.r2[bs.idx];
+                double c2 = (1.0 - bs.term1) * bs.kt[bs.idx] / (tc * bs.nf);
+                double term_2 = c2 * (rr2 + rr1 * rr1);
+                double term_3 = 2.0 * rr1 * sqrt(bs.term1 * c2);
+                scale = sqrt(bs.term1 + term_2 + term_3);
+            } else {
+                scale = sc->scale;
+            }
+        }
         double4 p = s.pos[k];
 #pragma unroll
         for (int c = 0; c < D; ++c) {

@@ -108,6 +108,7 @@ struct md_ctx {
         bool a_nvt = false;
         double a_nf = 0.0, a_term1 = 0.0;
         int64_t w_nsteps = 0, w_b0 = 0, w_prune_interval = 0; // the window being enqueued
+        bool w_scale_from_sums = false; // NVT: the next kick-drift forms the scale from kuw_dev (step_c was skipped)
         std::vector<int> w_prune_steps;
         // native transport (md_dom_comm_init): RCCL called by the library on the handle's stream
         ncclComm_t comm = nullptr;
@@ -802,7 +803,7 @@ void launch_force(md_ctx *c, bool want_uw, bool kick, double dt, int step, int r
         launch_force_d<2>(c, want_uw, kick, dt, step, rows);
 }
 
-void launch_kickdrift(md_ctx *c, bool nvt, double dt, bool check, int step)
+void launch_kickdrift(md_ctx *c, bool nvt, double dt, bool check, int step, BussiSrc bs = BussiSrc{})
 {
     int n = (int)c->n;
     DevState s = c->dev(c->cur);
@@ -814,14 +815,18 @@ void launch_kickdrift(md_ctx *c, bool nvt, double dt, bool check, int step)
     prof_begin(c, 1);
     if (c->dim == 3) {
         if (nvt)
-            k_kickdrift<3, true><<<nb, MD_BLOCK, 0, c->stream>>>(n, s, dt, skin_half, inner_half, use_d1, c->scal.p, step);
+            k_kickdrift<3, true><<<nb, MD_BLOCK, 0, c->stream>>>(n, s, dt, skin_half, inner_half, use_d1, c->scal.p, step,
+                                                                 bs);
         else
-            k_kickdrift<3, false><<<nb, MD_BLOCK, 0, c->stream>>>(n, s, dt, skin_half, inner_half, use_d1, c->scal.p, step);
+            k_kickdrift<3, false><<<nb, MD_BLOCK, 0, c->stream>>>(n, s, dt, skin_half, inner_half, use_d1, c->scal.p, step,
+                                                                 bs);
     } else {
         if (nvt)
-            k_kickdrift<2, true><<<nb, MD_BLOCK, 0, c->stream>>>(n, s, dt, skin_half, inner_half, use_d1, c->scal.p, step);
+            k_kickdrift<2, true><<<nb, MD_BLOCK, 0, c->stream>>>(n, s, dt, skin_half, inner_half, use_d1, c->scal.p, step,
+                                                                 bs);
         else
-            k_kickdrift<2, false><<<nb, MD_BLOCK, 0, c->stream>>>(n, s, dt, skin_half, inner_half, use_d1, c->scal.p, step);
+            k_kickdrift<2, false><<<nb, MD_BLOCK, 0, c->stream>>>(n, s, dt, skin_half, inner_half, use_d1, c->scal.p, step,
+                                                                 bs);
     }
     prof_end(c);
 }
@@ -2112,6 +2117,7 @@ int md_dom_async_begin(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, dou
     d.w_b0 = ctx->steps_since_build;
     d.w_prune_interval = prune_interval;
     d.w_prune_steps.clear();
+    d.w_scale_from_sums = false; // step 0 of a window takes the pending scale from sc->scale
     if (d.a_nvt) {
         if (!ktemp || !r1 || !r2) throw HipError("md_dom_async_begin: NVT needs ktemp, r1, r2");
         if (!(tau > 0.0) || !(nf > 0.0)) throw HipError("md_dom_async_begin: NVT needs tau > 0 and nf > 0");
@@ -2140,7 +2146,19 @@ int md_dom_step_a(md_ctx *ctx, double dt, int step)
     if (ctx->prune_on && ctx->inner_valid && d.w_prune_interval > 0 && ctx->steps_since_prune >= d.w_prune_interval)
         ctx->inner_valid = false;
     if (ctx->prune_on && !ctx->inner_valid) d.w_prune_steps.push_back(step);
-    if (ctx->n > 0) launch_kickdrift(ctx, true, dt, true, step);
+    BussiSrc bs{};
+    if (d.a_nvt && d.w_scale_from_sums) {
+        // the previous step's md_dom_step_c was skipped: its Bussi scale is formed here from the reduced sums
+        bs.sums = d.kuw_dev;
+        bs.kt = ctx->d_kt.p;
+        bs.r1 = ctx->d_r1.p;
+        bs.r2 = ctx->d_r2.p;
+        bs.nf = d.a_nf;
+        bs.term1 = d.a_term1;
+        bs.idx = step - 1;
+    }
+    d.w_scale_from_sums = d.a_nvt; // until md_dom_step_c runs for this step
+    if (ctx->n > 0) launch_kickdrift(ctx, true, dt, true, step, bs);
     DevState s = ctx->dev(ctx->cur);
     double shift_l = (d.rank == 0) ? ctx->L[0] : 0.0;
     double shift_r = (d.rank == d.nranks - 1) ? -ctx->L[0] : 0.0;
@@ -2183,6 +2201,7 @@ int md_dom_step_c(md_ctx *ctx, int step, int want_uw)
     auto &d = ctx->dom;
     k_dom_global_finalize<<<1, 1, 0, ctx->stream>>>(d.kuw_dev, want_uw, d.a_nvt ? 1 : 0, d.a_nf, d.a_term1, ctx->d_kt.p,
                                                     ctx->d_r1.p, ctx->d_r2.p, ctx->scal.p, step);
+    d.w_scale_from_sums = false; // sc->scale now holds this step's scale
     HIPCHK(hipGetLastError());
     API_END
 }
@@ -2367,8 +2386,12 @@ int md_dom_run_window(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, doub
         if (rc != 0) return rc;
         if (nvt || want) {
             g_rccl.check(g_rccl.AllReduce(d.kuw_dev, d.kuw_dev, 3, ncclFloat64, ncclSum, d.comm, st), "ncclAllReduce(K,U,W)");
-            rc = md_dom_step_c(ctx, (int)t, want);
-            if (rc != 0) return rc;
+            // the scalar kernel only where its results are read by the host or by the next window; in between the
+            // next kick-drift forms the Bussi scale from the reduced sums itself
+            if (want || t == nsteps - 1) {
+                rc = md_dom_step_c(ctx, (int)t, want);
+                if (rc != 0) return rc;
+            }
         }
     }
     return md_dom_async_end(ctx, apply_pending_scale, first_viol, uwk, info);

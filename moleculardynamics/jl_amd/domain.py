@@ -447,7 +447,8 @@ class DomainDevice:
                 self._chk(L.md_dom_step_b(h, float(dt), t, 1 if last else 0))
                 if nvt or last:
                     self.ex.allreduce_dev(self._kuw, "sum")
-                    self._chk(L.md_dom_step_c(h, t, 1 if last else 0))
+                    if last or t == wlen - 1:       # (in between, the next kick-drift forms the scale itself)
+                        self._chk(L.md_dom_step_c(h, t, 1 if last else 0))
             self._chk(L.md_dom_async_end(h, 1 if ends_run else 0, C.byref(fv), uwk, info))
 
         with torch.cuda.stream(self._stream):
