@@ -124,3 +124,47 @@ def test_nvt_temperature_ramp_through_the_driver(tmp_path):
     T = np.array([float(r[2]) for r in rows])
     assert abs(T[-1] - 1.0) < 0.08 and abs(T[3] - ramp(301)) < 0.15 and T[1] > T[3] > T[5] - 0.05
     st.system.device.close()
+
+
+@pytest.mark.parametrize("box,n,cutoff,skin", [
+    ((14.0, 9.5, 21.0), 2200, 2.5, None),      # three different cell counts per axis
+    ((31.0, 8.0, 8.2), 1500, 2.5, 0.2),        # a long thin box: 3 cells across, 12 along
+    ((40.0, 11.0), 380, 2.5, None),            # 2-D, anisotropic
+    ((9.1, 30.0, 9.1), 1700, 1.5, 0.0),        # CellListMap's default cutoff, rebuild-every-step cadence
+])
+def test_non_cubic_boxes(oracle, box, n, cutoff, skin):
+    """Orthorhombic cells with unequal edges (the reference takes any unit-cell matrix; diagonal ones are in scope):
+    forces, energy, pair set and a 25-step NVE trajectory against the oracle."""
+    from moleculardynamics.jl_amd import MDDevice
+    from moleculardynamics.jl_amd.initialization import initialize_velocities
+    box = np.array(box)
+    d = box.size
+    rng = np.random.default_rng(n)
+    # jittered lattice with per-axis spacing >= 1.0 (no overlaps), random particle order
+    m = np.maximum(1, np.floor(box / 1.02).astype(int))
+    while np.prod(m) < n:
+        raise AssertionError("test box too small for n")
+    g = np.stack(np.meshgrid(*[np.arange(k) for k in m], indexing="ij"), -1).reshape(-1, d)
+    g = g[rng.permutation(len(g))[:n]].astype(float)
+    x = (g + 0.5) * (box / m) + rng.uniform(-0.04, 0.04, (n, d))
+    v = initialize_velocities(1.0, rng, n, d)
+    diam = np.ones(n)
+    pot = oracle.make_pot(0, LJ)
+    f_ref, u_ref, w_ref, pairs_ref = oracle.forces_brute(x, box, cutoff, pot, diam, want_pairs=True)
+    ref = oracle.run(x, np.zeros((n, d), np.int32), v, f_ref, diam, box, cutoff, pot, 0.002, 25, use_cells=False)
+    with MDDevice(d, n, box, cutoff) as dev:
+        dev.set_potential(0, LJ)
+        if skin is not None:
+            dev.set_skin(skin)
+        dev.upload(x, v, f_ref, np.zeros((n, d), np.int32), diam)
+        u, w = dev.compute_forces()
+        _, _, f, _ = dev.download()
+        pairs = dev.neighbor_pairs()
+        dev.run(25, 0.002)
+        x2, v2, _, img2 = dev.download()
+    pr = pairs_ref[np.lexsort((pairs_ref[:, 1], pairs_ref[:, 0]))]
+    assert np.array_equal(pairs, pr)
+    assert np.abs(f - f_ref).max() <= 1e-11 * max(1.0, np.abs(f_ref).max())
+    assert abs(u - u_ref) <= 1e-12 * abs(u_ref) and abs(w - w_ref) <= 1e-12 * abs(w_ref)
+    assert np.array_equal(img2, ref["img"])
+    assert np.abs(x2 - ref["x"]).max() <= 1e-9 and np.abs(v2 - ref["v"]).max() <= 1e-9
