@@ -27,6 +27,18 @@ def main():
     nsteps = int(os.environ.get("DOM_STEPS", "60"))
     nvt = os.environ.get("DOM_NVT", "0") == "1"
     s = lj_system(n, kT=kT, permute=777)     # shuffled ids: ownership is by position, not by index
+    if os.environ.get("DOM_ELONG", "0") == "1":
+        # the weak-scaling bench's geometry: the global box is `world` cubes long in x
+        from moleculardynamics.jl_amd.initialization import lattice_positions
+        L1 = (n / world / 0.897) ** (1.0 / 3.0)
+        s["box"] = np.array([world * L1, L1, L1])
+        parts = []
+        for r in range(world):
+            xr = lattice_positions(n // world, np.full(3, L1), 3, np.random.default_rng(100 + r))
+            xr[:, 0] += r * L1
+            parts.append(xr)
+        s["x"] = np.ascontiguousarray(np.concatenate(parts)[np.random.default_rng(777).permutation((n // world) * world)])
+        assert s["x"].shape[0] == n
     if os.environ.get("DOM_POLY", "0") == "1":
         # per-particle diameters: the 32-byte LDS records and the diameter column of migrants / halo records
         s["diam"] = np.random.default_rng(5).uniform(0.9, 1.1, n)

@@ -38,17 +38,20 @@ def _launch(nproc, env_extra, port):
     (1, 0, "", "nccl-native-prune"), (1, 1, "", "nccl-native-prune"),
     # per-particle diameters (32-byte LDS records; the diameter travels with migrants and halo records)
     (2, 1, "device", "async-prune-poly"), (3, 0, "", "sync-poly"),
+    # the weak-scaling bench's geometry: one cube per rank, the global box `world` cubes long in x
+    (2, 1, "device", "async-prune-elong"), (3, 1, "device", "async-elong"),
 ])
 def test_slab_decomposition_matches_single_gpu(nproc, nvt, stage, mode):
     # N=8000 -> L=20.7: 2 slabs of 10.4, 3 slabs of 6.9 (>= 2 cells each); kT=2 and dt=0.002 make
     # particles migrate between slabs and cross the periodic faces within the run
     # stage == "device": exchange buffers live on the GPU (the RCCL-path plumbing) although gloo carries them
-    env = {"DOM_N": "8000", "DOM_KT": "2.0", "DOM_STEPS": "60", "DOM_NVT": str(nvt), "MDHIP_DOM_STAGE": stage,
+    env = {"DOM_KT": "2.0", "DOM_STEPS": "60", "DOM_NVT": str(nvt), "MDHIP_DOM_STAGE": stage,
            "DOM_ASYNC": "native" if "native" in mode else ("1" if "async" in mode else "0"),
            "DOM_PRUNE": "1" if "prune" in mode else "0", "DOM_STEPS": "120" if "prune" in mode else "60",
-           "DOM_POLY": "1" if mode.endswith("poly") else "0",
+           "DOM_POLY": "1" if mode.endswith("poly") else "0", "DOM_ELONG": "1" if mode.endswith("elong") else "0",
+           "DOM_N": "8232" if mode.endswith("elong") else "8000",      # 8232 = 2 * 4116 = 3 * 2744
            "DOM_BACKEND": "nccl" if mode.startswith("nccl") else "gloo"}
     port = 29511 + nproc + 10 * nvt + (20 if stage else 0) + {"sync": 0, "async": 40, "nccl-sync": 80, "nccl-async": 120,
                                                                 "nccl-native": 160, "nccl-native-prune": 200, "async-prune": 240, "async-prune-poly": 280,
-                                                                "sync-poly": 320}[mode]
+                                                                "sync-poly": 320, "async-prune-elong": 360, "async-elong": 400}[mode]
     _launch(nproc, env, port)
