@@ -168,3 +168,39 @@ def test_non_cubic_boxes(oracle, box, n, cutoff, skin):
     assert abs(u - u_ref) <= 1e-12 * abs(u_ref) and abs(w - w_ref) <= 1e-12 * abs(w_ref)
     assert np.array_equal(img2, ref["img"])
     assert np.abs(x2 - ref["x"]).max() <= 1e-9 and np.abs(v2 - ref["v"]).max() <= 1e-9
+
+
+def test_segmented_runs_equal_one_run(oracle):
+    """md_run in pieces (with downloads and a position-only re-upload in between, NVT noise sliced accordingly)
+    reproduces the single call and the oracle: the speculative windows, the prune/rebuild planner and the
+    persistent forces carry over call boundaries."""
+    from moleculardynamics.jl_amd import MDDevice, _lib
+    from tests.util import lj_system
+    n, nsteps, dt = 4096, 90, 0.002
+    s = lj_system(n, kT=1.5)
+    pot = oracle.make_pot(0, LJ)
+    rng = np.random.default_rng(17)
+    nf = 3 * (n - 1.0)
+    r1, r2 = rng.standard_normal(nsteps), 2.0 * rng.gamma((nf - 1) / 2, size=nsteps)
+    kt = np.linspace(1.5, 1.2, nsteps)
+    ref = oracle.run(s["x"], s["img"], s["v"], s["f"], s["diam"], s["box"], 2.5, pot, dt, nsteps, ensemble=1, tau=0.1,
+                     ktemp=kt, r1=r1, r2=r2, nthreads=4)
+    with MDDevice(3, n, s["box"], 2.5) as dev:
+        dev.set_potential(0, LJ)
+        dev.upload(s["x"], s["v"], s["f"], s["img"], s["diam"])
+        dev.run(nsteps, dt, _lib.MD_NVT, 0.1, nf, kt, r1, r2)
+        xa, va, fa, ia = dev.download()
+        dev.upload(s["x"], s["v"], s["f"], s["img"], s["diam"])
+        a = 0
+        for k, piece in enumerate([1, 6, 2, 31, 17, 33]):
+            dev.run(piece, dt, _lib.MD_NVT, 0.1, nf, kt[a:a + piece], r1[a:a + piece], r2[a:a + piece])
+            a += piece
+            x, v, f, im = dev.download()
+            if k == 3:
+                dev.upload(x=x, images=im)      # a position-only round trip (wrapped coordinates + images)
+        assert a == nsteps
+        xb, vb, fb, ib = dev.download()
+    for x, v, im in ((xa, va, ia), (xb, vb, ib)):
+        assert np.array_equal(im, ref["img"])
+        assert np.abs(x - ref["x"]).max() <= 1e-8 and np.abs(v - ref["v"]).max() <= 1e-8
+    assert np.abs(xa - xb).max() <= 1e-9 and np.abs(fa - fb).max() <= 1e-7 * max(1.0, np.abs(fa).max())
