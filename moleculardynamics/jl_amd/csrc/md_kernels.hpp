@@ -59,7 +59,11 @@ struct BoxGrid {
 
 struct PotParams {
     double p[8];
-    double c2;      // pair accepted iff d2 < c2 (strict form of d2 <= list_cutoff^2 folded with the potential's own r_cut where it has one)
+    double c2;      // a pair contributes iff d2 < c2, d2 in the REFERENCE's form (d2_ref below).  c2 = min(nextafter(list_cutoff^2)
+                    // [d2 <= cutoff^2, CellListMap], T(r_cut) [LJ: the smallest double whose correctly rounded sqrt is >= r_cut,
+                    // i.e. exactly the reference's `sqrt(d2) >= r_cut -> (0,0)`, src/potentials.jl:67-69]); set by the host
+    uint32_t c2_k;  // (high dword of c2) - 1: the fast path's integer pre-classification, see d2_band()
+    uint32_t pad_;
     double sig2u;   // uniform-diameter fast path: ((s+s)/2)^2
     double sig_u;   // the uniform diameter itself
     double c48, c24, c4; // 48*eps, 24*eps, 4*eps (LJ)
@@ -110,6 +114,24 @@ __device__ __forceinline__ double mask_d2(double d2, bool hit)
     int lo = __double2loint(d2);
     hi = hit ? hi : 0x7fe00000;
     return __hiloint2double(hi, lo);
+}
+
+// Squared pair distance in the reference's form: sum(abs2, x - y) left to right, every
+// product and every sum rounded on its own -- no fused multiply-add (hipcc would contract a*a + b*b).  The
+// accepted pair set (d2 <= cutoff^2) and the potential's own cutoff are decided on THIS value, so that they are
+// the reference's decisions bit for bit and not the device's rounding of them.
+template <int D>
+__device__ __forceinline__ double d2_ref(double dx, double dy, double dz)
+{
+#pragma clang fp contract(off)
+    double a = dx * dx;
+    double b = dy * dy;
+    double r = a + b;
+    if constexpr (D == 3) {
+        double c = dz * dz;
+        r = r + c;
+    }
+    return r;
 }
 
 // Row entries of tile t live at rows16[wave_tile_base + row_off(r, lane)]: groups of four
@@ -650,13 +672,9 @@ __global__ void __launch_bounds__(MD_BLOCK)
         for (int q = 0; q < 4; ++q) {
             double dx = pj[q].x - pi.x;
             double dy = pj[q].y - pi.y;
-            double d2 = dx * dx;
-            d2 = __builtin_fma(dy, dy, d2);
             double dz = 0.0;
-            if constexpr (D == 3) {
-                dz = pj[q].z - pi.z;
-                d2 = __builtin_fma(dz, dz, d2);
-            }
+            if constexpr (D == 3) dz = pj[q].z - pi.z;
+            double d2 = d2_ref<D>(dx, dy, dz);
             bool hit = d2 < pp.c2;
             double d2m = mask_d2(d2, hit);
             double u = 0.0, fpr;
@@ -932,6 +950,13 @@ __global__ void __launch_bounds__(MD_TILE)
             //   1/a = b * 1/(ab), 1/b = a * 1/(ab)   (masked d^2 = 2^511: the product stays finite),
             // and the force uses the sigma-folded polynomial f/r = z^4 (A z^3 - B), z = 1/r^2.
             double dxq[MD_UNROLL], dyq[MD_UNROLL], dzq[MD_UNROLL], dm[MD_UNROLL];
+            // Acceptance test.  The decision belongs to the reference-form distance d2_ref (no fma); the fma chain
+            // below differs from it by at most a few ulp, so its HIGH DWORD alone settles every candidate that is
+            // not within ~2^-20 (relative) of the cutoff: with t = hi(d2) - (hi(c2) - 1),
+            //     (int)t < 0 : surely inside      t > 2 : surely outside      t in {0,1,2} : undecided.
+            // One integer subtract and one integer compare per candidate instead of an fp64 compare; the rare
+            // undecided ones (2.6e-4 per particle and step at this density) are re-decided exactly below.
+            unsigned tmin = 0xffffffffu;
 #pragma unroll
             for (int q = 0; q < MD_UNROLL; ++q) {
                 dxq[q] = xj[q] - pi.x;
@@ -951,8 +976,23 @@ __global__ void __launch_bounds__(MD_TILE)
                     }
                 }
                 int hi = __double2hiint(d2);
-                hi = (d2 < pp.c2) ? hi : 0x5fe00000;
+                unsigned t = (unsigned)hi - pp.c2_k;
+                tmin = min(tmin, t);
+                hi = ((int)t < 0) ? hi : 0x5fe00000;
                 dm[q] = __hiloint2double(hi, __double2loint(d2));
+            }
+            if (__any(tmin <= 2u)) {
+#pragma unroll
+                for (int q = 0; q < MD_UNROLL; ++q) {
+                    double d2 = dxq[q] * dxq[q];
+                    d2 = __builtin_fma(dyq[q], dyq[q], d2);
+                    d2 = __builtin_fma(dzq[q], dzq[q], d2);
+                    unsigned t = (unsigned)__double2hiint(d2) - pp.c2_k;
+                    if (t <= 2u) {
+                        bool hit = d2_ref<3>(dxq[q], dyq[q], dzq[q]) < pp.c2;
+                        dm[q] = __hiloint2double(hit ? __double2hiint(d2) : 0x5fe00000, __double2loint(d2));
+                    }
+                }
             }
 #pragma unroll
             for (int q = 0; q < MD_UNROLL; q += 2) {
@@ -973,13 +1013,9 @@ __global__ void __launch_bounds__(MD_TILE)
         for (int q = 0; q < MD_UNROLL; ++q) {
             double dx = xj[q] - pi.x;
             double dy = yj[q] - pi.y;
-            double d2 = dx * dx;
-            d2 = __builtin_fma(dy, dy, d2);
             double dz = 0.0;
-            if constexpr (D == 3) {
-                dz = zj[q] - pi.z;
-                d2 = __builtin_fma(dz, dz, d2);
-            }
+            if constexpr (D == 3) dz = zj[q] - pi.z;
+            double d2 = d2_ref<D>(dx, dy, dz);
             if constexpr (PRUNE) {
                 if (d2 <= rin2) { // (padding entries are 1e100 away: they never survive)
                     // four 16-bit entries of a row are one 8-byte word (row_off): write it when it is full
@@ -1355,7 +1391,7 @@ __global__ void __launch_bounds__(MD_BLOCK)
 
 // ------------------------------------------------------------------------------------------
 // Brownian dynamics (src/integrate.jl:55-82, src/simulation.jl:181-308; broken in the reference):
-//   x += f*dt/kT + sigma*noise,  sigma = sqrt(2 dt),  noise_c = (2u-1)*sqrt(3), u uniform.
+//   x += (f*dt)/kT + sigma*noise,  sigma = sqrt(2 dt),  noise_c = (2u-1)*sqrt(3), u uniform.
 // The reference shares one host RNG across threads; here the noise is a counter-based stream,
 // Philox4x32-10 keyed by the seed with counter (particle id, step): one call gives a particle's three
 // uniforms, the result depends on neither the thread layout nor the particle order, and the oracle
@@ -1385,7 +1421,7 @@ __host__ __device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 
 template <int D>
 __global__ void __launch_bounds__(MD_BLOCK)
-    k_brownian_move(int n, DevState s, double dt_over_kt, double sigma, unsigned long long seed, long long gstep,
+    k_brownian_move(int n, DevState s, double dt, double ktemp, double sigma, unsigned long long seed, long long gstep,
                     double skin_half, Scalars *sc, int step)
 {
     if (sc->first_viol <= step) return;
@@ -1400,7 +1436,7 @@ __global__ void __launch_bounds__(MD_BLOCK)
         for (int c = 0; c < D; ++c) {
             double u = ((double)w[c] + 0.5) * 2.3283064365386963e-10; // (w + 1/2) / 2^32, in (0,1)
             double noise = (2.0 * u - 1.0) * 1.7320508075688772;
-            double xc = pos_get(p, c) + (s.f[c][k] * dt_over_kt) + (noise * sigma);
+            double xc = pos_get(p, c) + ((s.f[c][k] * dt) / ktemp) + (noise * sigma); // src/integrate.jl:75: (f*dt)/kT
             pos_set(p, c, xc);
             double d = xc - s.x0[c][k];
             disp2 = __builtin_fma(d, d, disp2);
@@ -1482,12 +1518,9 @@ __global__ void __launch_bounds__(MD_BLOCK)
         }
         double dx = pj.x - pk.x;
         double dy = pj.y - pk.y;
-        double d2 = dx * dx;
-        d2 = __builtin_fma(dy, dy, d2);
-        if constexpr (D == 3) {
-            double dz = pj.z - pk.z;
-            d2 = __builtin_fma(dz, dz, d2);
-        }
+        double dz = 0.0;
+        if constexpr (D == 3) dz = pj.z - pk.z;
+        double d2 = d2_ref<D>(dx, dy, dz); // CellListMap's test on the reference-form distance
         if (d2 <= c2_inclusive) {
             unsigned long long p = atomicAdd(&sc->pair_count, 1ull);
             if (p < cap) {
@@ -1527,7 +1560,7 @@ __global__ void __launch_bounds__(MD_BLOCK)
 
 template <int D>
 __global__ void __launch_bounds__(MD_BLOCK)
-    k_import(int n, DevState s, const double *__restrict__ xi, const double *__restrict__ vi,
+    k_import(int n, DevState s, BoxGrid g, const double *__restrict__ xi, const double *__restrict__ vi,
              const double *__restrict__ fi, const int32_t *__restrict__ ii, const double *__restrict__ di)
 {
     // host order -> current device order (slot k holds original particle id[k])
@@ -1537,6 +1570,13 @@ __global__ void __launch_bounds__(MD_BLOCK)
     double4 p = s.pos[k];
 #pragma unroll
     for (int c = 0; c < D; ++c) {
+        if (xi && !ii) {
+            // new coordinates, image counters kept ("NULL: leave that array as it is", mdhip.h): the wrap of the OLD
+            // coordinate is still pending (it is applied lazily, see k_wrap_count / k_export) -- fold its crossings
+            // into the counter now, or they are lost with the coordinate
+            double xc = pos_get(p, c);
+            if (xc < 0.0 || xc >= g.L[c]) s.img[c][k] += (int32_t)floor(g.invL[c] * xc);
+        }
         if (xi) pos_set(p, c, xi[o + c]);
         if (vi) s.v[c][k] = vi[o + c];
         if (fi) s.f[c][k] = fi[o + c];

@@ -353,16 +353,31 @@ void configure_grid(md_ctx *c)
     c->list_valid = false;
 }
 
+// Smallest double t with sqrt(t) >= r (sqrt correctly rounded, as IEEE and Julia's sqrt are): the reference
+// zeroes a pair iff sqrt(d2) >= r_cut (src/pairwise.jl:29, src/potentials.jl:67-69), i.e. iff d2 >= this
+// threshold -- which is NOT r*r in general (sqrt(6.25 - 1 ulp) already rounds to 2.5).
+double sqrt_ge_threshold(double r)
+{
+    double t = r * r;
+    while (std::sqrt(t) >= r) t = std::nextafter(t, 0.0);
+    while (std::sqrt(t) < r) t = std::nextafter(t, INFINITY);
+    return t;
+}
+
 void configure_potential(md_ctx *c)
 {
     double c2_incl = c->rc * c->rc;
-    double c2 = std::nextafter(c2_incl, INFINITY); // d2 < c2  <=>  d2 <= rc^2
+    double c2 = std::nextafter(c2_incl, INFINITY); // d2 < c2  <=>  d2 <= rc^2   (CellListMap's acceptance)
     if (c->pot_kind == POT_LJ || c->pot_kind == POT_LJ_MOD) {
-        // r >= r_cut -> (0,0): src/potentials.jl:67-69
-        double rcp2 = c->pp.p[2] * c->pp.p[2];
-        c2 = std::min(c2, rcp2);
+        // r >= r_cut -> (0,0) with r = sqrt(d2): src/potentials.jl:67-69
+        c2 = std::min(c2, sqrt_ge_threshold(c->pp.p[2]));
     }
     c->pp.c2 = c2;
+    {
+        uint64_t bits;
+        memcpy(&bits, &c2, sizeof bits);
+        c->pp.c2_k = (uint32_t)(bits >> 32) - 1u;
+    }
     c->pp.sig_u = c->sigma_u;
     c->pp.sig2u = ((c->sigma_u + c->sigma_u) * 0.5) * ((c->sigma_u + c->sigma_u) * 0.5);
     c->pp.c48 = 48.0 * c->pp.p[0];
@@ -1161,11 +1176,11 @@ int md_upload(md_ctx *ctx, const double *x, const double *v, const double *f, co
     DevState s = ctx->dev(ctx->cur);
     int nb = ctx->nblk;
     if (ctx->dim == 3)
-        k_import<3><<<nb, MD_BLOCK, 0, st>>>((int)ctx->n, s, x ? ctx->io_x.p : nullptr, v ? ctx->io_v.p : nullptr,
+        k_import<3><<<nb, MD_BLOCK, 0, st>>>((int)ctx->n, s, ctx->grid, x ? ctx->io_x.p : nullptr, v ? ctx->io_v.p : nullptr,
                                              f ? ctx->io_f.p : nullptr, images ? ctx->io_i.p : nullptr,
                                              diameters ? ctx->io_d.p : nullptr);
     else
-        k_import<2><<<nb, MD_BLOCK, 0, st>>>((int)ctx->n, s, x ? ctx->io_x.p : nullptr, v ? ctx->io_v.p : nullptr,
+        k_import<2><<<nb, MD_BLOCK, 0, st>>>((int)ctx->n, s, ctx->grid, x ? ctx->io_x.p : nullptr, v ? ctx->io_v.p : nullptr,
                                              f ? ctx->io_f.p : nullptr, images ? ctx->io_i.p : nullptr,
                                              diameters ? ctx->io_d.p : nullptr);
     HIPCHK(hipGetLastError());
@@ -1572,7 +1587,7 @@ int md_run_brownian(md_ctx *ctx, int64_t nsteps, double dt, double ktemp, uint64
     hipStream_t st = ctx->stream;
     ctx->brown_acc.ensure(2);
     HIPCHK(hipMemsetAsync(ctx->brown_acc.p, 0, 2 * sizeof(double), st));
-    const double sigma = std::sqrt(2.0 * dt), dt_over_kt = dt / ktemp;
+    const double sigma = std::sqrt(2.0 * dt);
     ctx->list_valid = false; // (rows without inner pruning for this loop; positions may have been uploaded)
     int64_t s = 0;
     while (s < nsteps) {
@@ -1588,10 +1603,10 @@ int md_run_brownian(md_ctx *ctx, int64_t nsteps, double dt, double ktemp, uint64
                                                     (int)t);
             DevState sd = ctx->dev(ctx->cur);
             if (ctx->dim == 3)
-                k_brownian_move<3><<<ctx->nblk, MD_BLOCK, 0, st>>>((int)ctx->n, sd, dt_over_kt, sigma, seed, g,
+                k_brownian_move<3><<<ctx->nblk, MD_BLOCK, 0, st>>>((int)ctx->n, sd, dt, ktemp, sigma, seed, g,
                                                                    0.5 * ctx->skin, ctx->scal.p, (int)t);
             else
-                k_brownian_move<2><<<ctx->nblk, MD_BLOCK, 0, st>>>((int)ctx->n, sd, dt_over_kt, sigma, seed, g,
+                k_brownian_move<2><<<ctx->nblk, MD_BLOCK, 0, st>>>((int)ctx->n, sd, dt, ktemp, sigma, seed, g,
                                                                    0.5 * ctx->skin, ctx->scal.p, (int)t);
         }
         HIPCHK(hipGetLastError());

@@ -20,13 +20,18 @@
  * i's component c lives at a[i*d + c] (what a Julia Matrix{Float64}(d,N) or a
  * Vector{MVector{d}} packed contiguously looks like).
  *
- * Canonical pair geometry (shared bit-for-bit with the HIP path):
+ * Canonical pair geometry -- the REFERENCE's form, not the device's:
  *   for the ordered pair (a -> b), per component c:
  *     d0 = x_b - x_a ; s = (d0 > L/2) ? -1 : (d0 < -L/2) ? +1 : 0
- *     xb' = x_b + s*L          (the translated ghost copy, rounded once)
+ *     xb' = x_b + s*L          (CellListMap's translated ghost copy, rounded once)
  *     del = xb' - x_a
- *   d2 = fma(del_z,del_z, fma(del_y,del_y, del_x*del_x))      (3-D)
- *   d2 = fma(del_y,del_y, del_x*del_x)                         (2-D)
+ *   d2 = (del_x*del_x + del_y*del_y) + del_z*del_z     summed left to right, every product and
+ *   d2 =  del_x*del_x + del_y*del_y           (2-D)     sum rounded: NO fused multiply-add -- what
+ *                                                       Julia's sum(abs2, x - y) on an SVector computes
+ * (this file is compiled with -ffp-contract=off).  A pair is accepted iff d2 <= cutoff^2; the
+ * potential then sees d = sqrt(d2) and applies its own `r >= r_cut -> (0,0)` to that d
+ * (src/potentials.jl:67-69).  The HIP path has to reproduce these two decisions exactly -- it
+ * may not bend them to its own rounding (round 1 did: VERDICT.md).
  * The unordered pair {i,j} is oriented a=min(i,j), b=max(i,j).
  */
 #include <math.h>
@@ -209,9 +214,9 @@ static inline double canon_d2(int dim, const double *xa, const double *xb, const
         double xbp = xb[c] + s * L[c];
         del[c] = xbp - xa[c];
     }
-    double d2 = del[0] * del[0];
-    d2 = fma(del[1], del[1], d2);
-    if (dim == 3) d2 = fma(del[2], del[2], d2);
+    /* sum(abs2, del), left to right, each operation rounded (no FMA: -ffp-contract=off) */
+    double d2 = del[0] * del[0] + del[1] * del[1];
+    if (dim == 3) d2 = d2 + del[2] * del[2];
     return d2;
 }
 
@@ -731,7 +736,7 @@ int oracle_run_brownian(int dim, int n, double *x, int32_t *img, double *f, cons
 {
     double invL[3];
     for (int c = 0; c < dim; ++c) invL[c] = 1.0 / L[c];
-    const double sigma = sqrt(2.0 * dt), dt_over_kt = dt / ktemp;
+    const double sigma = sqrt(2.0 * dt);
     double U = 0.0, W = 0.0, vsum = 0.0, vcnt = 0.0;
     for (int s = 0; s < nsteps; ++s) {
         int64_t g = first_step + s;
@@ -751,7 +756,7 @@ int oracle_run_brownian(int dim, int n, double *x, int32_t *img, double *f, cons
                 size_t k = (size_t)i * dim + c;
                 double u = ((double)w[c] + 0.5) * 2.3283064365386963e-10;
                 double noise = (2.0 * u - 1.0) * 1.7320508075688772;
-                x[k] = x[k] + (f[k] * dt_over_kt) + (noise * sigma);
+                x[k] = x[k] + (f[k] * dt / ktemp) + (noise * sigma); /* src/integrate.jl:75: (f*dt)/kT */
                 x[k] = wrap1(x[k], &img[k], L[c], invL[c]);
             }
         }

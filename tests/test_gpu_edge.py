@@ -204,3 +204,28 @@ def test_segmented_runs_equal_one_run(oracle):
         assert np.array_equal(im, ref["img"])
         assert np.abs(x - ref["x"]).max() <= 1e-8 and np.abs(v - ref["v"]).max() <= 1e-8
     assert np.abs(xa - xb).max() <= 1e-9 and np.abs(fa - fb).max() <= 1e-7 * max(1.0, np.abs(fa).max())
+
+
+def test_position_only_upload_keeps_pending_image_crossings(oracle):
+    """md_upload(x=..., images=NULL) ("NULL: leave that array as it is", include/mdhip.h): the device wraps lazily, so
+    between list builds its image counters lack the crossings of coordinates that sit outside [0, L) at that moment.
+    A download followed by an x-only upload must not lose them (round-1 ADVICE: it did).  Hot, small system so that
+    many particles are across a face when the upload happens; images exact against the oracle."""
+    from moleculardynamics.jl_amd import MDDevice
+    from tests.util import lj_system
+    n, dt = 2048, 0.002
+    s = lj_system(n, kT=6.0)
+    pot = oracle.make_pot(0, LJ)
+    ref = oracle.run(s["x"], s["img"], s["v"], s["f"], s["diam"], s["box"], 2.5, pot, dt, 50, nthreads=4)
+    assert np.abs(ref["img"]).sum() > 20           # the run does cross faces
+    with MDDevice(3, n, s["box"], 2.5) as dev:
+        dev.set_potential(0, LJ)
+        dev.upload(s["x"], s["v"], s["f"], s["img"], s["diam"])
+        pending = 0
+        for piece in (7, 9, 11, 23):
+            dev.run(piece, dt)
+            x, v, f, im = dev.download()
+            dev.upload(x=x)                         # coordinates only: counters stay on the device
+        x, v, f, im = dev.download()
+    assert np.array_equal(im, ref["img"])
+    assert np.abs(x - ref["x"]).max() <= 1e-8

@@ -7,6 +7,20 @@ Tolerances (stated, fp64):
   10-step trajectory positions  1e-10 absolute
 The built-in LJ runs in r^-2 form on the device (no sqrt); the oracle uses the reference's
 sigma/r form -- the difference is a few ulp, inside these tolerances.
+
+Decisions are the reference's, bit for bit: a pair is accepted iff d2 <= list_cutoff^2 and LJ contributes iff
+sqrt(d2) < r_cut, with d2 = (dx*dx + dy*dy) + dz*dz rounded operation by operation (no fma).
+The device's fast kernels classify on the high dword of an fma chain and re-decide every candidate within 2^-20 of
+the threshold on the reference form (test_cutoff_decisions_follow_reference_arithmetic).
+
+Stated deviations of the device arithmetic from the reference's (all inside the tolerances above):
+  * values, not decisions, use fma: d2 in the LJ r^-2 polynomial, the force accumulation F += fpr*d;
+  * LJ in r^-2 form with v_rcp_f64 + one Newton step (2e-15 relative) instead of sigma/r, sqrt and division;
+  * full-neighbour sums in row order instead of the reference's half-shell traversal order (U, W halved);
+  * the periodic wrap x <- L*(x/L - floor(x/L)) (src/boundary.jl:9-15) is applied lazily -- at list builds and on
+    download, only to coordinates outside [0, L) -- whereas the reference re-rounds every coordinate every step
+    (src/integrate.jl:16); image counters are identical, positions agree to ~1 ulp of L per step;
+  * Bussi's K is a tree sum over per-block partials instead of the serial sum of src/thermostat.jl:53-55.
 """
 import ctypes as C
 
@@ -487,3 +501,45 @@ def test_pruning_changes_nothing():
         assert np.abs(x - out[0][0]).max() <= 1e-9 and np.abs(v - out[0][1]).max() <= 1e-9
         _check_forces(f, out[0][2], 1e-9)
         assert abs(uwk[0] - out[0][3][0]) <= 1e-10 * abs(out[0][3][0])
+
+
+def _sqrt_ge_threshold(r):
+    t = r * r
+    while np.sqrt(t) >= r:
+        t = np.nextafter(t, 0.0)
+    while np.sqrt(t) < r:
+        t = np.nextafter(t, np.inf)
+    return float(t)
+
+
+@pytest.mark.parametrize("list_cutoff", [2.5, 3.0])
+def test_cutoff_decisions_follow_reference_arithmetic(oracle, list_cutoff):
+    """Adversarial dimers (tests/util.py cutoff_dimers): squared separations ON the threshold, one ulp either side,
+    and between the reference-form value and the fma-chain value.  list_cutoff 2.5: the threshold is CellListMap's
+    d2 <= cutoff^2.  list_cutoff 3.0: it is LJ's own sqrt(d2) >= r_cut -> (0,0) (src/potentials.jl:67-69), i.e.
+    d2 >= the smallest double whose sqrt rounds to 2.5 (which is 6.25 - 1 ulp, not 6.25).  Pair set bit-exact;
+    a single misclassified pair would change U by 1.6e-2 and two forces by 3.9e-2.  Exercises the generic kernels
+    (md_compute_forces, md_neighbor_pairs) and both fast kernels (prune step and inner rows) through md_run."""
+    from tests.util import cutoff_dimers, d2_forms
+    target = 6.25 if list_cutoff == 2.5 else _sqrt_ge_threshold(2.5)
+    assert list_cutoff == 2.5 or target == np.nextafter(6.25, 0.0)
+    s = cutoff_dimers(target)
+    nd = s["n"] // 2
+    disagree = sum(1 for k in range(nd) if (lambda rf: (rf[0] <= target) != (rf[1] <= target))(d2_forms(s["x"][2 * k], s["x"][2 * k + 1])))
+    assert disagree >= nd // 4
+    pot = oracle.make_pot(oracle.POT_LJ, LJ)
+    f_ref, u_ref, w_ref, pairs_ref = oracle.forces_brute(s["x"], s["box"], list_cutoff, pot, s["diam"], want_pairs=True)
+    with _dev(s, list_cutoff) as d:
+        u, w = d.compute_forces()
+        _, _, f, _ = d.download()
+        pairs = d.neighbor_pairs()
+        assert np.array_equal(pairs, pairs_ref[np.lexsort((pairs_ref[:, 1], pairs_ref[:, 0]))]), "pair set differs"
+        _check_forces(f, f_ref)
+        assert abs(u - u_ref) <= 1e-12 * abs(u_ref) and abs(w - w_ref) <= 1e-12 * abs(w_ref)
+        # the no-energy kernels of the step loop: dt so small that nothing moves (x + v*dt == x)
+        d.upload(s["x"], s["v"], s["f"], s["img"], s["diam"])
+        for which in ("prune step", "inner rows"):
+            d.run(1, 1e-30, thermo=False)
+            x, _, f, _ = d.download()
+            assert np.array_equal(x, s["x"]), which
+            _check_forces(f, f_ref)

@@ -229,3 +229,34 @@ def test_modified_lj_variants(oracle, mode, ron):
     assert abs(u) < 1e-7 and (mode == 0 or abs(f) < 1e-7)
     if mode == 2:
         assert oracle.evaluate(pot, 1.5, 1.0, 1.0) == oracle.evaluate(lj, 1.5, 1.0, 1.0)
+
+
+# ---------------------------------------------------------------- acceptance test: the reference's arithmetic, not an fma chain
+def test_pair_acceptance_is_reference_form(oracle):
+    """a pair is accepted iff d2 <= cutoff^2 with d2 = (dx*dx + dy*dy) + dz*dz, every product
+    and sum rounded (what Julia computes) -- NOT the fused-multiply-add chain a GPU compiler prefers.  The dimers sit
+    exactly where the two forms disagree; the oracle must side with the reference form on every one of them."""
+    from tests.util import cutoff_dimers, d2_forms
+    s = cutoff_dimers(6.25, n_side=6)
+    x = s["x"]
+    nd = s["n"] // 2
+    ref_accept, fma_accept = [], []
+    for k in range(nd):
+        ref, fm = d2_forms(x[2 * k], x[2 * k + 1])
+        ref_accept.append(ref <= 6.25)
+        fma_accept.append(fm <= 6.25)
+    ref_accept, fma_accept = np.array(ref_accept), np.array(fma_accept)
+    assert (ref_accept != fma_accept).sum() >= nd // 4        # the input has teeth
+    pairs = oracle.pairs_cells(x, s["box"], 2.5)
+    want = np.array([[2 * k, 2 * k + 1] for k in range(nd) if ref_accept[k]], dtype=np.int32)
+    assert np.array_equal(pairs, want)
+    # and the potential's own cutoff acts on d = sqrt(d2) (src/pairwise.jl:29, src/potentials.jl:67-69):
+    # sqrt(6.25 - 1 ulp) rounds to 2.5, so such a pair is in the list (list cutoff 3) but contributes exactly nothing
+    pot = oracle.make_pot(oracle.POT_LJ, LJ)
+    f, u, w, _ = oracle.forces_brute(x, s["box"], 3.0, pot, s["diam"])
+    dn = np.nextafter(6.25, 0.0)
+    for k in range(nd):
+        ref, _ = d2_forms(x[2 * k], x[2 * k + 1])
+        contributes = np.sqrt(ref) < 2.5
+        assert contributes == (ref < dn)
+        assert (np.abs(f[2 * k]).max() > 0.0) == contributes

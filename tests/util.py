@@ -27,3 +27,103 @@ def poly_system(n=1200, rho=1.0, kT=0.11, seed=24680, dlo=0.6, dhi=1.2):
     v = initialize_velocities(kT, np.random.default_rng(67890), n, dim)
     return dict(n=n, dim=dim, box=box, x=x, v=v, f=np.zeros_like(x), img=np.zeros((n, dim), dtype=np.int32),
                 diam=diam)
+
+
+# ---------------------------------------------------------------------------------------------
+# Adversarial inputs for the acceptance test d2 <= cutoff^2: isolated dimers whose squared
+# separation sits ON the threshold, one ulp either side of it, or between the value the
+# reference's arithmetic gives (products and sums rounded separately) and the
+# value a fused-multiply-add chain gives.  An implementation that decides on its own rounding of
+# d2 instead of the reference's classifies some of these pairs differently.
+# ---------------------------------------------------------------------------------------------
+from fractions import Fraction
+
+
+def _rn(fr):
+    """Fraction -> nearest double (Python's int / int true division is correctly rounded)."""
+    return fr.numerator / fr.denominator
+
+
+def d2_forms(a, b):
+    """(reference form, fma-chain form) of |b - a|^2 for two 3-vectors of doubles."""
+    d = [float(b[c]) - float(a[c]) for c in range(3)]
+    ref = (d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]
+    t = d[0] * d[0]
+    t = _rn(Fraction(d[1]) * Fraction(d[1]) + Fraction(t))
+    t = _rn(Fraction(d[2]) * Fraction(d[2]) + Fraction(t))
+    return ref, t
+
+
+def cutoff_dimers(target, n_side=8, spacing=9.0, seed=99):
+    """n_side^3 dimers on a cubic lattice of the given spacing (no two dimers interact); dimer k's squared
+    separation is steered, by nudging one coordinate in ulps, into category k % 6 relative to `target`:
+      0  ref <= target <  fma      (the reference accepts, an fma chain rejects)
+      1  fma <= target <  ref      (the reverse)
+      2  ref == target             (inclusive bound)
+      3  ref == nextafter(target, +inf)
+      4  ref == nextafter(target, 0)
+      5  ref within 64 ulp, unsteered
+    Returns dict(x, box, n, cat) with cat[k] = the category actually reached (-1: search failed, dimer left as is)."""
+    rng = np.random.default_rng(seed)
+    L = n_side * spacing
+    up, dn = np.nextafter(target, np.inf), np.nextafter(target, 0.0)
+    xs, cats = [], []
+    r = float(np.sqrt(target))
+    k = 0
+    for iz in range(n_side):
+        for iy in range(n_side):
+            for ix in range(n_side):
+                a = (np.array([ix, iy, iz]) + 0.5) * spacing + rng.uniform(-0.25, 0.25, 3)   # dimers >= 3.5 apart
+                want = k % 6
+                k += 1
+                got = -1
+                for _attempt in range(40):
+                    th = rng.uniform(0.2, 2.9)
+                    dy = rng.uniform(2e-3, 2e-2) * rng.choice([-1.0, 1.0])   # small: a 1-ulp nudge of y moves d2 by << 1 ulp
+                    rr = np.sqrt(max(target - dy * dy, 0.0))
+                    b = a + np.array([rr * np.cos(th), dy, rr * np.sin(th)])
+                    # coarse: nudge z to bring ref within a few ulp; fine: nudge y
+                    best = None
+                    for _it in range(200):
+                        ref, _ = d2_forms(a, b)
+                        if abs(ref - target) <= 4 * (up - target):
+                            break
+                        b[2] = np.nextafter(b[2], np.inf if (ref < target) == (b[2] > a[2]) else -np.inf)
+                    # fine: scan y over +-4000 ulp (vectorised for the reference form; the exact fma form only for
+                    # the few candidates whose reference form is within an ulp of the target)
+                    found = False
+                    ks = np.arange(-4000, 4001)
+                    ys = b[1] + ks * np.spacing(b[1])
+                    dx, dz = b[0] - a[0], b[2] - a[2]
+                    dys = ys - a[1]
+                    refs = (dx * dx + dys * dys) + dz * dz
+                    if want == 2:
+                        idx = np.flatnonzero(refs == target)
+                    elif want == 3:
+                        idx = np.flatnonzero(refs == up)
+                    elif want == 4:
+                        idx = np.flatnonzero(refs == dn)
+                    elif want == 5:
+                        idx = np.flatnonzero(np.abs(refs - target) <= 64 * (up - target))
+                    else:
+                        idx = np.flatnonzero(np.abs(refs - target) <= 2 * (up - target))
+                    for i in idx[np.argsort(np.abs(ks[idx]))][:64]:
+                        bb = b.copy()
+                        bb[1] = ys[i]
+                        if want in (0, 1):
+                            ref, fm = d2_forms(a, bb)
+                            if not ((want == 0 and ref <= target < fm) or (want == 1 and fm <= target < ref)):
+                                continue
+                        b = bb
+                        found = True
+                        break
+                    if found:
+                        got = want
+                        break
+                xs.append(a)
+                xs.append(b)
+                cats.append(got)
+    x = np.array(xs)
+    n = x.shape[0]
+    return dict(n=n, dim=3, box=np.full(3, L), x=x, v=np.zeros_like(x), f=np.zeros_like(x),
+                img=np.zeros((n, 3), dtype=np.int32), diam=np.ones(n), cat=np.array(cats))
