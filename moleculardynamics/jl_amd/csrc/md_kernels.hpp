@@ -833,89 +833,18 @@ __global__ void __launch_bounds__(MD_TILE)
 // evaluation over inner rows sums the same terms in the same order as one over the outer rows (the
 // LJ fast path below pairs neighbouring candidates for a shared reciprocal, which makes the two agree to
 // rounding rather than bit for bit).
-template <int D, int POT, bool UNIFORM, bool WANT_UW, bool KICK, bool PRUNE>
-__global__ void __launch_bounds__(MD_TILE)
-    k_force_tile(int n, DevState s, PotParams pp, const uint16_t *__restrict__ nlist16, int maxn,
-                 const int32_t *__restrict__ nmax_tile, const uint32_t *__restrict__ halo, int hcap,
-                 const int32_t *__restrict__ halo_count, double dt, double *__restrict__ partials, int nblk_total,
-                 Scalars *__restrict__ sc, int step, uint16_t *__restrict__ rows_in, int32_t *__restrict__ nmax_in,
-                 double rin2)
+// The pair loop of the tiled kernels: one lane per particle walks its row of 16-bit LDS offsets, MD_UNROLL
+// candidates per iteration.  Shared by k_force_tile (forces at the stored positions) and k_step_tile (a whole
+// velocity-Verlet step).  PRUNE: the kept entries (d2 <= rin2) are appended to the lane's inner row as it goes.
+template <int D, int POT, bool UNIFORM, bool WANT_UW, bool PRUNE>
+__device__ __forceinline__ void tile_pair_loop(const unsigned char *smem, const ushort4 *row4,
+                                               ushort4 (&jn)[MD_UNROLL / 4], int m, int H,
+                                               const double4 &pi, const PotParams &pp, unsigned long long *rin64,
+                                               double rin2, unsigned long long &acc, int &cin, double &fx, double &fy,
+                                               double &fz, double &us, double &ws)
 {
     constexpr int RS = UNIFORM ? 24 : 32;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ double red[16];
-    if (sc->first_viol <= step) return;
-    int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const double4 *__restrict__ P = s.pos;
-    int H = halo_count[bid];
-    const uint32_t *hl = halo + (size_t)bid * hcap;
-    // this thread's own loads (row length, first index groups, position, velocity) go out ahead of the
-    // staging so that their latency is covered by it
-    int k = bid * MD_TILE + threadIdx.x;
-    bool active = k < n;
-    int kk = active ? k : n - 1;
-    int lane = threadIdx.x & 63;
-    int wt = bid * (MD_TILE / 64) + (threadIdx.x >> 6);
-    const ushort4 *row4 = (const ushort4 *)(nlist16 + ((size_t)wt * maxn) * 64) + lane;
-    unsigned long long *rin64 = PRUNE ? (unsigned long long *)(rows_in + ((size_t)wt * maxn) * 64) + lane : nullptr;
-    unsigned long long acc = 0ull;
-    int cin = 0;
-    int m = nmax_tile[wt];
-    double4 pi = P[kk];
-    constexpr int G = MD_UNROLL / 4; // index groups per iteration
-    ushort4 jn[G];
-#pragma unroll
-    for (int g = 0; g < G; ++g) jn[g] = row4[(size_t)((4 * g < m) ? g : 0) * 64];
-    double v0[3] = {0.0, 0.0, 0.0};
-    if constexpr (KICK) {
-#pragma unroll
-        for (int c = 0; c < D; ++c) v0[c] = s.v[c][kk];
-    }
-    // stage the halo: all of a thread's index loads are issued first, then all its gathers, so that the
-    // dependent index -> record chain is paid once per 8 records instead of once per record
-    for (int h0 = 0; h0 <= H; h0 += 8 * MD_TILE) {
-        uint32_t idx[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            int h = h0 + i * MD_TILE + threadIdx.x;
-            idx[i] = (h < H) ? hl[h] : 0xffffffffu;
-        }
-        // A halo entry is a slot (26 bits) plus a periodic shift code (6 bits, see shifted()): with virtual
-        // ghosts the slot is the ghost's OWNER and the ghost's coordinates x_owner + s*L are formed here, the
-        // same single addition k_ghost_update would have done -- so nothing has to refresh ghost records
-        // between the drift and this kernel.
-        double4 pr[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            pr[i] = (idx[i] != 0xffffffffu) ? P[idx[i] & 0x3ffffffu]
-                                            : make_double4(MD_SENTINEL_POS, MD_SENTINEL_POS, MD_SENTINEL_POS, 1.0);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            uint32_t code = (idx[i] != 0xffffffffu) ? (idx[i] >> 26) : 0u;
-            if (code) {
-                uint32_t sx = code & 3u, sy = (code >> 2) & 3u, sz = (code >> 4) & 3u;
-                if (sx == 1u) pr[i].x = pr[i].x + s.boxL[0];
-                if (sx == 2u) pr[i].x = pr[i].x - s.boxL[0];
-                if (sy == 1u) pr[i].y = pr[i].y + s.boxL[1];
-                if (sy == 2u) pr[i].y = pr[i].y - s.boxL[1];
-                if (sz == 1u) pr[i].z = pr[i].z + s.boxL[2];
-                if (sz == 2u) pr[i].z = pr[i].z - s.boxL[2];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            int h = h0 + i * MD_TILE + threadIdx.x;
-            if (h <= H) {
-                double *rec = (double *)(smem + (size_t)h * RS);
-                rec[0] = pr[i].x;
-                rec[1] = pr[i].y;
-                rec[2] = (D == 3) ? pr[i].z : 0.0;
-                if constexpr (!UNIFORM) rec[3] = pr[i].w;
-            }
-        }
-    }
-    __syncthreads();
-    double fx = 0.0, fy = 0.0, fz = 0.0, us = 0.0, ws = 0.0;
+    constexpr int G = MD_UNROLL / 4; // index groups per iteration; jn holds the first G groups, loaded by the caller
     // Two index groups (8 candidates) per iteration: all their LDS reads are issued before the first
     // use, which is what hides the LDS latency at 4 waves per SIMD.  The indices of the next pair of
     // groups are fetched while this one is computed.  A row has a multiple of 4 entries; when the
@@ -1040,7 +969,17 @@ __global__ void __launch_bounds__(MD_TILE)
             }
         }
     }
-    if constexpr (PRUNE) {
+}
+
+// PRUNE epilogue: pad the inner row to the wave's longest, record the prune positions x1 and the largest
+// displacement since the build.
+template <int D, bool UNIFORM>
+__device__ __forceinline__ void tile_prune_tail(DevState &s, Scalars *sc, int H, int k, bool active, int lane, int wt,
+                                                const double4 &pi, unsigned long long *rin64, int32_t *nmax_in,
+                                                unsigned long long acc, int cin)
+{
+    constexpr int RS = UNIFORM ? 24 : 32;
+    {
         // pad the inner row to the wave's longest (a multiple of 4) with the sentinel record
         const unsigned long long sent = (unsigned long long)(H * RS);
         const unsigned long long sent4 = sent | (sent << 16) | (sent << 32) | (sent << 48);
@@ -1067,6 +1006,93 @@ __global__ void __launch_bounds__(MD_TILE)
         double wm = wave_max_d(dd);
         if (lane == 0 && wm > 0.0) atomicMax(&sc->d1max2_bits, (unsigned long long)__double_as_longlong(wm));
     }
+}
+
+template <int D, int POT, bool UNIFORM, bool WANT_UW, bool KICK, bool PRUNE>
+__global__ void __launch_bounds__(MD_TILE)
+    k_force_tile(int n, DevState s, PotParams pp, const uint16_t *__restrict__ nlist16, int maxn,
+                 const int32_t *__restrict__ nmax_tile, const uint32_t *__restrict__ halo, int hcap,
+                 const int32_t *__restrict__ halo_count, double dt, double *__restrict__ partials, int nblk_total,
+                 Scalars *__restrict__ sc, int step, uint16_t *__restrict__ rows_in, int32_t *__restrict__ nmax_in,
+                 double rin2)
+{
+    constexpr int RS = UNIFORM ? 24 : 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ double red[16];
+    if (sc->first_viol <= step) return;
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const double4 *__restrict__ P = s.pos;
+    int H = halo_count[bid];
+    const uint32_t *hl = halo + (size_t)bid * hcap;
+    // this thread's own loads (row length, first index groups, position, velocity) go out ahead of the
+    // staging so that their latency is covered by it
+    int k = bid * MD_TILE + threadIdx.x;
+    bool active = k < n;
+    int kk = active ? k : n - 1;
+    int lane = threadIdx.x & 63;
+    int wt = bid * (MD_TILE / 64) + (threadIdx.x >> 6);
+    const ushort4 *row4 = (const ushort4 *)(nlist16 + ((size_t)wt * maxn) * 64) + lane;
+    unsigned long long *rin64 = PRUNE ? (unsigned long long *)(rows_in + ((size_t)wt * maxn) * 64) + lane : nullptr;
+    unsigned long long acc = 0ull;
+    int cin = 0;
+    int m = nmax_tile[wt];
+    double4 pi = P[kk];
+    constexpr int G = MD_UNROLL / 4; // index groups per iteration
+    ushort4 jn[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) jn[g] = row4[(size_t)((4 * g < m) ? g : 0) * 64];
+    double v0[3] = {0.0, 0.0, 0.0};
+    if constexpr (KICK) {
+#pragma unroll
+        for (int c = 0; c < D; ++c) v0[c] = s.v[c][kk];
+    }
+    // stage the halo: all of a thread's index loads are issued first, then all its gathers, so that the
+    // dependent index -> record chain is paid once per 8 records instead of once per record
+    for (int h0 = 0; h0 <= H; h0 += 8 * MD_TILE) {
+        uint32_t idx[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int h = h0 + i * MD_TILE + threadIdx.x;
+            idx[i] = (h < H) ? hl[h] : 0xffffffffu;
+        }
+        // A halo entry is a slot (26 bits) plus a periodic shift code (6 bits, see shifted()): with virtual
+        // ghosts the slot is the ghost's OWNER and the ghost's coordinates x_owner + s*L are formed here, the
+        // same single addition k_ghost_update would have done -- so nothing has to refresh ghost records
+        // between the drift and this kernel.
+        double4 pr[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            pr[i] = (idx[i] != 0xffffffffu) ? P[idx[i] & 0x3ffffffu]
+                                            : make_double4(MD_SENTINEL_POS, MD_SENTINEL_POS, MD_SENTINEL_POS, 1.0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            uint32_t code = (idx[i] != 0xffffffffu) ? (idx[i] >> 26) : 0u;
+            if (code) {
+                uint32_t sx = code & 3u, sy = (code >> 2) & 3u, sz = (code >> 4) & 3u;
+                if (sx == 1u) pr[i].x = pr[i].x + s.boxL[0];
+                if (sx == 2u) pr[i].x = pr[i].x - s.boxL[0];
+                if (sy == 1u) pr[i].y = pr[i].y + s.boxL[1];
+                if (sy == 2u) pr[i].y = pr[i].y - s.boxL[1];
+                if (sz == 1u) pr[i].z = pr[i].z + s.boxL[2];
+                if (sz == 2u) pr[i].z = pr[i].z - s.boxL[2];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int h = h0 + i * MD_TILE + threadIdx.x;
+            if (h <= H) {
+                double *rec = (double *)(smem + (size_t)h * RS);
+                rec[0] = pr[i].x;
+                rec[1] = pr[i].y;
+                rec[2] = (D == 3) ? pr[i].z : 0.0;
+                if constexpr (!UNIFORM) rec[3] = pr[i].w;
+            }
+        }
+    }
+    __syncthreads();
+    double fx = 0.0, fy = 0.0, fz = 0.0, us = 0.0, ws = 0.0;
+    tile_pair_loop<D, POT, UNIFORM, WANT_UW, PRUNE>(smem, row4, jn, m, H, pi, pp, rin64, rin2, acc, cin, fx, fy, fz, us, ws);
+    if constexpr (PRUNE) tile_prune_tail<D, UNIFORM>(s, sc, H, k, active, lane, wt, pi, rin64, nmax_in, acc, cin);
     double ke = 0.0;
     if (active) {
         s.f[0][k] = fx;
@@ -1100,6 +1126,240 @@ __global__ void __launch_bounds__(MD_TILE)
             partials[2 * nblk_total + bid] = tw;
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// The fused step kernel: ONE launch per velocity-Verlet step (plus the one-block k_finalize when a thermostat or a
+// thermo line needs the global sums).  The classic sequence k_kickdrift -> k_force_tile streams every particle
+// through HBM twice per step; here the first half-kick and the drift are folded into the staging of the force
+// kernel's halo, and the second half-kick into its epilogue:
+//
+//   state after step n-1, per particle (buffer A, AoS record "rec"):   p = x + (dt^2/2) f ,  v' = v after the
+//   second half-kick, BEFORE the thermostat's rescale   (+ the diameter for non-uniform systems), and f (SoA).
+//   With alpha = the pending Bussi scale of step n-1 (src/thermostat.jl:36-45; 1 for NVE):
+//       v_half = alpha v' + (f dt)/2          src/integrate.jl:14    (own particle only)
+//       x_n    = p + (alpha dt) v'            src/integrate.jl:15    == x + v_half dt, one fma; computed for the
+//                                              tile's own particles AND, identically, for every halo particle
+//                                              while its record is staged into LDS
+//       f_n    = pair loop over the LDS image  src/pairwise.jl:26-39
+//       v'_n   = v_half + (f_n dt)/2          src/integrate.jl:33 ;  p_n = x_n + (dt^2/2) f_n  -> buffer B
+//   and the per-block partials of sum v'^2 (U, W on thermo steps) for k_finalize.
+// Buffers alternate (A <-> B) from step to step, so a step whose displacement check fails -- the check runs here,
+// on the tile's own x_n -- has destroyed nothing: the host refreshes the rows and launches the step again from A.
+// The positions x_n also go to a plain double4 array (posB) for everything that is not this kernel (list build,
+// download, the parity exports).  Rounding: x_n is one fma of (p, v') instead of the reference's two rounded
+// operations; a stated deviation at the 1-ulp level, inside the trajectory tolerance.
+// ------------------------------------------------------------------------------------------
+struct StepBufs {
+    const double *recA;
+    double *recB;
+    const double *fA[3];
+    double *fB[3];
+    double4 *posB;
+};
+
+template <int D, int POT, bool UNIFORM, bool WANT_UW, bool PRUNE>
+__global__ void __launch_bounds__(MD_TILE)
+    k_step_tile(int n, DevState s, StepBufs sb, PotParams pp, const uint16_t *__restrict__ nlist16, int maxn,
+                const int32_t *__restrict__ nmax_tile, const uint32_t *__restrict__ halo, int hcap,
+                const int32_t *__restrict__ halo_count, double dt, double skin_half, double inner_half, int use_d1,
+                double *__restrict__ partials, int nblk_total, Scalars *__restrict__ sc, int step,
+                uint16_t *__restrict__ rows_in, int32_t *__restrict__ nmax_in, double rin2,
+                long long *__restrict__ stamps)
+{
+#define MD_SSTAMP(i)                                                                                   \
+    do {                                                                                               \
+        if (stamps && (threadIdx.x & 63) == 0)                                                         \
+            stamps[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (i)] = (long long)clock64();   \
+    } while (0)
+    constexpr int RS = UNIFORM ? 24 : 32;
+    constexpr int RG = UNIFORM ? 6 : 8; // doubles per state record
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ double red[16];
+    // (strictly earlier: a violation found by another block of THIS launch must not stop the blocks behind it --
+    // every block writes its x_n, which the host needs to decide between a prune and a rebuild)
+    if (sc->first_viol < step) return;
+    MD_SSTAMP(0);
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    int H = halo_count[bid];
+    const uint32_t *hl = halo + (size_t)bid * hcap;
+    int k = bid * MD_TILE + threadIdx.x;
+    bool active = k < n;
+    int kk = active ? k : n - 1;
+    int lane = threadIdx.x & 63;
+    int wt = bid * (MD_TILE / 64) + (threadIdx.x >> 6);
+    const ushort4 *row4 = (const ushort4 *)(nlist16 + ((size_t)wt * maxn) * 64) + lane;
+    unsigned long long *rin64 = PRUNE ? (unsigned long long *)(rows_in + ((size_t)wt * maxn) * 64) + lane : nullptr;
+    unsigned long long acc = 0ull;
+    int cin = 0;
+    int m = nmax_tile[wt];
+    const double alpha = sc->scale;
+    const double adt = alpha * dt;
+    // own record, previous forces, reference positions of the rows in use
+    const double2 *ra = (const double2 *)(sb.recA + (size_t)kk * RG);
+    double2 a0 = ra[0], a1 = ra[1], a2 = ra[2]; // (p.x p.y) (p.z v'.x) (v'.y v'.z)
+    double sig_own = pp.sig_u;
+    if constexpr (!UNIFORM) sig_own = ra[3].x;
+    double fprev[3] = {0.0, 0.0, 0.0}, xr[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        fprev[c] = sb.fA[c][kk];
+        xr[c] = PRUNE ? s.x0[c][kk] : s.x1[c][kk];
+    }
+    constexpr int G = MD_UNROLL / 4;
+    ushort4 jn[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) jn[g] = row4[(size_t)((4 * g < m) ? g : 0) * 64];
+    MD_SSTAMP(1);
+    // stage the halo: index loads, then the record gathers, then drift + periodic shift + LDS writes
+    for (int h0 = 0; h0 <= H; h0 += 8 * MD_TILE) {
+        uint32_t idx[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int h = h0 + i * MD_TILE + threadIdx.x;
+            idx[i] = (h < H) ? hl[h] : 0xffffffffu;
+        }
+        double2 r0[8], r1[8], r2[8], r3[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const double2 *rb = (const double2 *)(sb.recA + (size_t)(idx[i] & 0x3ffffffu) * RG);
+            bool ok = idx[i] != 0xffffffffu;
+            if (!ok) rb = (const double2 *)sb.recA;
+            r0[i] = rb[0];
+            r1[i] = rb[1];
+            r2[i] = rb[2];
+            if constexpr (!UNIFORM) r3[i] = rb[3];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int h = h0 + i * MD_TILE + threadIdx.x;
+            bool ok = idx[i] != 0xffffffffu;
+            double x = __builtin_fma(adt, r1[i].y, r0[i].x);
+            double y = __builtin_fma(adt, r2[i].x, r0[i].y);
+            double z = (D == 3) ? __builtin_fma(adt, r2[i].y, r1[i].x) : 0.0;
+            uint32_t code = ok ? (idx[i] >> 26) : 0u;
+            if (code) {
+                uint32_t sx = code & 3u, sy = (code >> 2) & 3u, sz = (code >> 4) & 3u;
+                if (sx == 1u) x = x + s.boxL[0];
+                if (sx == 2u) x = x - s.boxL[0];
+                if (sy == 1u) y = y + s.boxL[1];
+                if (sy == 2u) y = y - s.boxL[1];
+                if (sz == 1u) z = z + s.boxL[2];
+                if (sz == 2u) z = z - s.boxL[2];
+            }
+            if (!ok) {
+                x = MD_SENTINEL_POS;
+                y = MD_SENTINEL_POS;
+                z = (D == 3) ? MD_SENTINEL_POS : 0.0;
+            }
+            if (h <= H) {
+                double *rec = (double *)(smem + (size_t)h * RS);
+                rec[0] = x;
+                rec[1] = y;
+                rec[2] = z;
+                if constexpr (!UNIFORM) rec[3] = ok ? r3[i].x : 1.0;
+            }
+        }
+    }
+    // the tile's own particles (their loads went out ahead of the staging): first half-kick, drift, validity check
+    const double pown[3] = {a0.x, a0.y, a1.x}, vown[3] = {a1.y, a2.x, a2.y};
+    double vh[3] = {0.0, 0.0, 0.0}, xn[3] = {0.0, 0.0, 0.0};
+    double disp2 = 0.0;
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        vh[c] = alpha * vown[c] + (fprev[c] * dt) / 2.0;
+        xn[c] = __builtin_fma(adt, vown[c], pown[c]);
+        double d = xn[c] - xr[c];
+        disp2 = __builtin_fma(d, d, disp2);
+    }
+    const double4 pi = make_double4(xn[0], xn[1], xn[2], sig_own);
+    if (active) sb.posB[k] = pi;
+    {
+        // validity of the rows this step walks (see k_kickdrift): within min(inner/2, skin/2 - d1) of the prune
+        // positions x1; a prune step walks the outer rows: within skin/2 of the build positions x0
+        double d1 = use_d1 ? sqrt(__longlong_as_double((long long)sc->d1max2_bits)) : 0.0;
+        double thr = fmin(inner_half, skin_half - d1);
+        double thr2 = thr > 0.0 ? thr * thr : -1.0;
+        if (__any(active && disp2 > thr2)) {
+            if (lane == 0) atomicMin(&sc->first_viol, step);
+        }
+    }
+    MD_SSTAMP(2);
+    __syncthreads();
+    MD_SSTAMP(3);
+    double fx = 0.0, fy = 0.0, fz = 0.0, us = 0.0, ws = 0.0;
+    tile_pair_loop<D, POT, UNIFORM, WANT_UW, PRUNE>(smem, row4, jn, m, H, pi, pp, rin64, rin2, acc, cin, fx, fy, fz, us, ws);
+    MD_SSTAMP(4);
+    if constexpr (PRUNE) tile_prune_tail<D, UNIFORM>(s, sc, H, k, active, lane, wt, pi, rin64, nmax_in, acc, cin);
+    double ke = 0.0;
+    if (active) {
+        const double fn[3] = {fx, fy, fz};
+        const double h2 = (dt * dt) / 2.0;
+        double vp[3] = {0.0, 0.0, 0.0}, pn[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            sb.fB[c][k] = fn[c];
+            vp[c] = vh[c] + (fn[c] * dt) / 2.0;
+            pn[c] = __builtin_fma(h2, fn[c], xn[c]);
+            ke += vp[c] * vp[c];
+        }
+        double2 *rb = (double2 *)(sb.recB + (size_t)k * RG);
+        rb[0] = make_double2(pn[0], pn[1]);
+        rb[1] = make_double2(pn[2], vp[0]);
+        rb[2] = make_double2(vp[1], vp[2]);
+        if constexpr (!UNIFORM) rb[3] = make_double2(sig_own, 0.0);
+    } else {
+        us = 0.0;
+        ws = 0.0;
+    }
+    {
+        double t = block_sum(ke, red);
+        if (threadIdx.x == 0) partials[bid] = t;
+    }
+    if constexpr (WANT_UW) {
+        double tu = block_sum(us, red);
+        double tw = block_sum(ws, red);
+        if (threadIdx.x == 0) {
+            partials[nblk_total + bid] = tu;
+            partials[2 * nblk_total + bid] = tw;
+        }
+    }
+    MD_SSTAMP(5);
+#undef MD_SSTAMP
+}
+
+// state arrays <-> step records (start and end of a fused step loop, and around a list build inside it)
+template <int D, bool UNIFORM>
+__global__ void __launch_bounds__(MD_BLOCK) k_fuse(int n, DevState s, double *__restrict__ rec, double h2)
+{
+    constexpr int RG = UNIFORM ? 6 : 8;
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    double4 p = s.pos[k];
+    double pp3[3] = {p.x, p.y, (D == 3) ? p.z : 0.0}, v3[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        pp3[c] = __builtin_fma(h2, s.f[c][k], pp3[c]);
+        v3[c] = s.v[c][k];
+    }
+    double2 *rb = (double2 *)(rec + (size_t)k * RG);
+    rb[0] = make_double2(pp3[0], pp3[1]);
+    rb[1] = make_double2(pp3[2], v3[0]);
+    rb[2] = make_double2(v3[1], v3[2]);
+    if constexpr (!UNIFORM) rb[3] = make_double2(p.w, 0.0);
+}
+
+template <int D, bool UNIFORM>
+__global__ void __launch_bounds__(MD_BLOCK)
+    k_unfuse(int n, DevState s, const double *__restrict__ rec, const Scalars *sc, int apply_scale)
+{
+    constexpr int RG = UNIFORM ? 6 : 8;
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const double *r = rec + (size_t)k * RG;
+    double scale = apply_scale ? sc->scale : 1.0;
+#pragma unroll
+    for (int c = 0; c < D; ++c) s.v[c][k] = r[3 + c] * scale;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -13,6 +13,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -181,6 +182,11 @@ struct md_ctx {
     DBuf<uint16_t> nlist16_in;
     DBuf<int32_t> nmax_tile_in;
     int64_t steps_since_prune = 0;
+    // fused step loop (k_step_tile): ping-pong state records; `fz_a` = the buffer set that holds the latest complete
+    // step: records rec[fz_a], forces sb[cur ^ fz_a].f, positions sb[cur ^ fz_a].pos  (set 0 is the canonical state)
+    DBuf<double> rec[2];
+    int fz_a = 0;
+    bool allow_fused = true;
     double d1_rate = 0.0;       // growth per step of the largest displacement since a reference (measured)
     bool rate_known = false;
     double safety = 0.97;       // fraction of the validity radii the plan uses
@@ -865,6 +871,173 @@ void launch_finalize(md_ctx *c, bool want_uw, bool nvt, double nf, double term1,
                                           c->d_r1.p, c->d_r2.p, c->scal.p, step);
 }
 
+// ---- fused step loop (k_step_tile) ---------------------------------------------------------------------------
+bool fused_available(md_ctx *c)
+{
+    return c->allow_fused && c->use_tiles && c->virtual_ghosts && !c->dom.on && c->pot_kind != POT_CUSTOM && c->skin > 0.0;
+}
+
+bool fused_uniform(md_ctx *c)
+{
+    return c->uniform_sigma && c->pot_kind != POT_POLYDISPERSE && c->pot_kind != POT_LJ_MOD;
+}
+
+// canonical state arrays -> records of buffer set 0
+void fused_enter(md_ctx *c, double dt)
+{
+    int n = (int)c->n;
+    const bool uni = fused_uniform(c);
+    const size_t rg = uni ? 6 : 8;
+    for (int w = 0; w < 2; ++w) c->rec[w].ensure((size_t)c->ncap * rg);
+    DevState s = c->dev(c->cur);
+    double h2 = (dt * dt) / 2.0;
+    if (c->dim == 3) {
+        if (uni)
+            k_fuse<3, true><<<c->nblk, MD_BLOCK, 0, c->stream>>>(n, s, c->rec[0].p, h2);
+        else
+            k_fuse<3, false><<<c->nblk, MD_BLOCK, 0, c->stream>>>(n, s, c->rec[0].p, h2);
+    } else {
+        if (uni)
+            k_fuse<2, true><<<c->nblk, MD_BLOCK, 0, c->stream>>>(n, s, c->rec[0].p, h2);
+        else
+            k_fuse<2, false><<<c->nblk, MD_BLOCK, 0, c->stream>>>(n, s, c->rec[0].p, h2);
+    }
+    c->fz_a = 0;
+}
+
+// latest buffer set -> canonical state arrays (velocities optionally with the pending Bussi rescale applied)
+void fused_leave(md_ctx *c, bool apply_scale)
+{
+    int n = (int)c->n;
+    const bool uni = fused_uniform(c);
+    if (c->fz_a) {
+        // the latest positions / forces live in the other StateBufs' arrays: make them this one's
+        StateBufs &a = c->sb[c->cur], &b = c->sb[c->cur ^ 1];
+        std::swap(a.pos.p, b.pos.p);
+        std::swap(a.pos.n, b.pos.n);
+        for (int d = 0; d < c->dim; ++d) {
+            std::swap(a.f[d].p, b.f[d].p);
+            std::swap(a.f[d].n, b.f[d].n);
+        }
+    }
+    DevState s = c->dev(c->cur);
+    const double *rec = c->rec[c->fz_a].p;
+    int ap = apply_scale ? 1 : 0;
+    if (c->dim == 3) {
+        if (uni)
+            k_unfuse<3, true><<<c->nblk, MD_BLOCK, 0, c->stream>>>(n, s, rec, c->scal.p, ap);
+        else
+            k_unfuse<3, false><<<c->nblk, MD_BLOCK, 0, c->stream>>>(n, s, rec, c->scal.p, ap);
+    } else {
+        if (uni)
+            k_unfuse<2, true><<<c->nblk, MD_BLOCK, 0, c->stream>>>(n, s, rec, c->scal.p, ap);
+        else
+            k_unfuse<2, false><<<c->nblk, MD_BLOCK, 0, c->stream>>>(n, s, rec, c->scal.p, ap);
+    }
+    c->fz_a = 0;
+}
+
+template <int D, int POT, bool UNIFORM>
+void launch_step_tpu(md_ctx *c, bool want_uw, double dt, int step)
+{
+    int n = (int)c->n;
+    int nb = c->nblk;
+    bool prune_step = c->prune_on && !c->inner_valid;
+    bool use_inner = c->inner_valid;
+    const uint16_t *rows16 = use_inner ? c->nlist16_in.p : c->nlist16.p;
+    const int32_t *rowmax = use_inner ? c->nmax_tile_in.p : c->nmax_tile.p;
+    // displacement limits of the rows this step walks (k_kickdrift's rule)
+    double skin_half = 0.5 * c->skin;
+    double inner_half = use_inner ? 0.5 * c->inner_skin : 0.5 * c->skin;
+    int use_d1 = use_inner ? 1 : 0;
+    DevState s = c->dev(c->cur); // x1 = the prune positions while the inner rows are valid, else x0
+    double rin = c->rc + c->inner_skin;
+    if (prune_step) {
+        for (int d = 0; d < 3; ++d) s.x1[d] = c->x1[d].p; // the prune step writes the new reference positions
+        k_reset_d1<<<1, 1, 0, c->stream>>>(c->scal.p, step - 1);
+    }
+    const int a = c->fz_a;
+    StateBufs &A = c->sb[c->cur ^ a], &B = c->sb[c->cur ^ a ^ 1];
+    StepBufs sbufs{};
+    sbufs.recA = c->rec[a].p;
+    sbufs.recB = c->rec[a ^ 1].p;
+    for (int d = 0; d < 3; ++d) {
+        sbufs.fA[d] = A.f[d].p;
+        sbufs.fB[d] = B.f[d].p;
+    }
+    sbufs.posB = B.pos.p;
+#define LS(UW, PR)                                                                                                  \
+    do {                                                                                                            \
+        auto kfn = k_step_tile<D, POT, UNIFORM, UW, PR>;                                                            \
+        static int attr_dev_mask = 0;                                                                               \
+        if (!(attr_dev_mask & (1 << (c->device & 31)))) {                                                           \
+            HIPCHK(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,               \
+                                       (int)(160 * 1024 - 256)));                                                   \
+            attr_dev_mask |= 1 << (c->device & 31);                                                                 \
+        }                                                                                                           \
+        kfn<<<nb, MD_TILE, c->tile_lds, c->stream>>>(n, s, sbufs, c->pp, rows16, c->maxn, rowmax, c->halo.p, c->hcap, \
+                                                     c->halo_count.p, dt, skin_half, inner_half, use_d1,            \
+                                                     c->partials.p, nb, c->scal.p, step, c->nlist16_in.p,           \
+                                                     c->nmax_tile_in.p, rin * rin, c->dbg_stamps.p);                \
+    } while (0)
+    prof_begin(c);
+    if (prune_step) {
+        if (want_uw)
+            LS(true, true);
+        else
+            LS(false, true);
+    } else {
+        if (want_uw)
+            LS(true, false);
+        else
+            LS(false, false);
+    }
+    prof_end(c);
+#undef LS
+    c->fz_a ^= 1;
+    if (prune_step) {
+        c->inner_valid = true;
+        c->steps_since_prune = 0;
+        c->st_prunes++;
+    }
+}
+
+template <int D>
+void launch_step_d(md_ctx *c, bool want_uw, double dt, int step)
+{
+    bool u = c->uniform_sigma;
+    switch (c->pot_kind) {
+    case POT_LJ:
+        if (u)
+            launch_step_tpu<D, POT_LJ, true>(c, want_uw, dt, step);
+        else
+            launch_step_tpu<D, POT_LJ, false>(c, want_uw, dt, step);
+        break;
+    case POT_PSEUDOHS:
+        if (u)
+            launch_step_tpu<D, POT_PSEUDOHS, true>(c, want_uw, dt, step);
+        else
+            launch_step_tpu<D, POT_PSEUDOHS, false>(c, want_uw, dt, step);
+        break;
+    case POT_POLYDISPERSE:
+        launch_step_tpu<D, POT_POLYDISPERSE, false>(c, want_uw, dt, step);
+        break;
+    case POT_LJ_MOD:
+        launch_step_tpu<D, POT_LJ_MOD, false>(c, want_uw, dt, step);
+        break;
+    default:
+        throw HipError("fused step loop: potential kind not available");
+    }
+}
+
+void launch_step(md_ctx *c, bool want_uw, double dt, int step)
+{
+    if (c->dim == 3)
+        launch_step_d<3>(c, want_uw, dt, step);
+    else
+        launch_step_d<2>(c, want_uw, dt, step);
+}
+
 Scalars read_scalars(md_ctx *c)
 {
     Scalars h;
@@ -951,6 +1124,7 @@ static int create_common(int dim, int64_t n_global, int64_t n_cap, bool domain, 
         if (const char *e = getenv("MDHIP_NO_TILES")) ctx->allow_tiles = !(e[0] == '1');
         if (const char *e = getenv("MDHIP_NO_FUSED_BUILD")) ctx->allow_fused_build = !(e[0] == '1');
         if (const char *e = getenv("MDHIP_INNER_SKIN")) ctx->inner_skin_req = atof(e);
+        if (const char *e = getenv("MDHIP_NO_FUSED_STEP")) ctx->allow_fused = !(e[0] == '1');
         // default potential: LennardJones() -- src/potentials.jl:52-64
         ctx->pot_kind = POT_LJ;
         ctx->pp.p[0] = 1.0;
@@ -992,7 +1166,7 @@ static int create_common(int dim, int64_t n_global, int64_t n_cap, bool domain, 
         ctx->nlist16.alloc((size_t)ctx->ntiles * ctx->maxn * 64);
         ctx->halo.alloc((size_t)nblk_cap * ctx->hcap);
         ctx->halo_count.alloc(nblk_cap);
-        if (getenv("MDHIP_STAMPS")) ctx->dbg_stamps.alloc((size_t)nblk_cap * 10);
+        if (getenv("MDHIP_STAMPS")) ctx->dbg_stamps.alloc((size_t)nblk_cap * 32);
         ctx->partials.alloc((size_t)3 * nblk_cap);
         HIPCHK(hipMemsetAsync(ctx->partials.p, 0, sizeof(double) * 3 * nblk_cap, ctx->stream));
         ctx->scal.alloc(1);
@@ -1293,6 +1467,29 @@ int md_run(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, double tau, dou
         launch_force(ctx, uw, true, dt, t);
         if (nvt || uw) launch_finalize(ctx, uw, nvt, nf, term1, t);
     };
+    // The fused loop (k_step_tile: one launch per step) whenever the tiled rows exist; the
+    // classic three-kernel sequence otherwise (slab handles, user potentials, rows that do not fit LDS, skin 0).
+    bool fused = ctx->skin > 0.0 && fused_available(ctx);
+    if (fused) fused_enter(ctx, dt);
+    auto step_part = [&](int t) {
+        if (!fused) {
+            launch_kickdrift(ctx, nvt, dt, true, t);
+            launch_ghost_update(ctx, t);
+            force_part(t);
+            return;
+        }
+        bool last = (t == (int)nsteps - 1);
+        bool uw = last && want;
+        launch_step(ctx, uw, dt, t);
+        if (nvt || uw) launch_finalize(ctx, uw, nvt, nf, term1, t);
+    };
+    // list build at a step boundary of the fused loop: records -> state arrays, build (permutes them), -> records
+    auto fused_rebuild = [&]() {
+        fused_leave(ctx, false);
+        rebuild(ctx);
+        fused = fused_available(ctx);
+        if (fused) fused_enter(ctx, dt);
+    };
     if (ctx->skin <= 0.0) {
         // literal reference cadence: a fresh linked-cell build every step
         for (int t = 0; t < (int)nsteps; ++t) {
@@ -1314,9 +1511,10 @@ int md_run(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, double tau, dou
         //     1.1 * rate * (L - 1) <= safety * inner/2   (inner rows valid between two prunes)
         // with the segments evened out, L = ceil(R / ceil(R / Lmax)).  The device checks are the exact
         // criteria; the plan only has to make violations rare, and `safety` backs off when they happen.
-        auto measure_disp0 = [&]() -> double {
+        auto measure_disp0 = [&](double4 *pos_override = nullptr) -> double {
             k_reset_disp0<<<1, 1, 0, st>>>(ctx->scal.p);
             DevState sd = ctx->dev(ctx->cur);
+            if (pos_override) sd.pos = pos_override;
             if (ctx->dim == 3)
                 k_max_disp0<3><<<ctx->nblk, MD_BLOCK, 0, st>>>((int)ctx->n, sd, ctx->scal.p);
             else
@@ -1360,6 +1558,7 @@ int md_run(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, double tau, dou
             int win_cap = (int)std::min<int64_t>(nsteps, (int64_t)s + std::max<int64_t>(1, R - ctx->steps_since_build));
             prune_steps.clear();
             int last_prune = -1;
+            const int a_win = ctx->fz_a; // fused: the buffer set step s reads
             for (int t = s; t < win_cap; ++t) {
                 if (pruning && ctx->inner_valid && ctx->steps_since_prune >= L)
                     ctx->inner_valid = false; // scheduled refresh of the inner rows
@@ -1367,9 +1566,7 @@ int md_run(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, double tau, dou
                     prune_steps.push_back(t);
                     last_prune = t;
                 }
-                launch_kickdrift(ctx, nvt, dt, true, t);
-                launch_ghost_update(ctx, t);
-                force_part(t); // (a prune step marks the inner rows valid and zeroes steps_since_prune)
+                step_part(t); // (a prune step marks the inner rows valid and zeroes steps_since_prune)
                 ctx->steps_since_prune += 1;
             }
             int win_end = win_cap;
@@ -1397,17 +1594,28 @@ int md_run(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, double tau, dou
                 for (int p : prune_steps)
                     if (p == m) m_was_prune = true;
                 ctx->steps_since_build += (m - s) + 1;
+                // fused loop: step m's launch read buffer set a_m and wrote the other one -- x_m included, which is
+                // what the displacement is measured on; the state proper is still step m-1's, in set a_m
+                const bool was_fused = fused;
+                double4 *pos_m = nullptr;
+                if (fused) {
+                    ctx->fz_a = a_win ^ ((m - s) & 1);
+                    pos_m = ctx->sb[ctx->cur ^ ctx->fz_a ^ 1].pos.p;
+                }
                 bool rebuilt;
                 if (!pruning) {
                     int64_t observed = ctx->steps_since_build;
                     ctx->target_interval = std::max<int64_t>(2, (observed * 4) / 5);
-                    rebuild(ctx);
+                    if (fused)
+                        fused_rebuild();
+                    else
+                        rebuild(ctx);
                     rebuilt = true;
                 } else {
                     ctx->safety = std::max(0.5, ctx->safety - 0.02);
                     // the largest displacement since the build is both a fresh sample of the rate and the exact
                     // test of whether the outer rows can still serve a prune step at the drifted positions
-                    double d0 = measure_disp0();
+                    double d0 = measure_disp0(pos_m);
                     double sample = d0 / (double)ctx->steps_since_build;
                     if (!ctx->rate_known)
                         ctx->d1_rate = sample;
@@ -1416,7 +1624,10 @@ int md_run(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, double tau, dou
                     ctx->rate_known = true;
                     // (a prune this late would buy only a few steps: rebuild unless a full segment still fits)
                     if (m_was_prune || !(d0 + 0.5 * ctx->inner_skin <= 0.5 * ctx->skin)) {
-                        rebuild(ctx);
+                        if (fused)
+                            fused_rebuild();
+                        else
+                            rebuild(ctx);
                         rebuilt = true;
                     } else {
                         ctx->inner_valid = false;
@@ -1429,7 +1640,14 @@ int md_run(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, double tau, dou
                     k_reset_viol<<<1, 1, 0, st>>>(ctx->scal.p);
                     launch_ghost_update(ctx, -1);
                 }
-                force_part(m);
+                if (was_fused) {
+                    // the whole of step m again, from the state of step m-1 (a fused build happens at the step
+                    // boundary: the rows are one step old when step m uses them)
+                    step_part(m);
+                    if (rebuilt) ctx->steps_since_build = 1;
+                } else {
+                    force_part(m);
+                }
                 ctx->steps_since_prune = 1;
                 s = m + 1;
             } else {
@@ -1445,18 +1663,46 @@ int md_run(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, double tau, dou
                         if (last_prune >= 0 && b_last > 0)
                             ctx->d1_rate = 0.7 * ctx->d1_rate + 0.3 * (d1 / (double)b_last);
                         ctx->safety = std::min(0.99, ctx->safety + 0.002);
-                        if (s < (int)nsteps && ctx->steps_since_build >= R) rebuild(ctx);
+                        if (s < (int)nsteps && ctx->steps_since_build >= R) {
+                            if (fused)
+                                fused_rebuild();
+                            else
+                                rebuild(ctx);
+                        }
                     }
                 } else if (s < (int)nsteps && ctx->steps_since_build >= ctx->target_interval) {
                     // scheduled rebuild just ahead of the expected violation; creep the interval up so that it
                     // tracks the true one from below
-                    rebuild(ctx);
+                    if (fused)
+                        fused_rebuild();
+                    else
+                        rebuild(ctx);
                     ctx->target_interval += 1;
                 }
             }
         }
     }
-    if (nvt) {
+    if (fused && ctx->dbg_stamps.p) {
+        // MDHIP_STAMPS=1: phase cycle counts of the LAST fused launch, averaged over its waves
+        std::vector<long long> hs((size_t)ctx->nblk * 4 * 8);
+        HIPCHK(hipMemcpyAsync(hs.data(), ctx->dbg_stamps.p, hs.size() * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        double acc[6] = {0};
+        long long t0 = LLONG_MAX, t1 = 0;
+        for (size_t w = 0; w < (size_t)ctx->nblk * 4; ++w) {
+            for (int i = 1; i <= 5; ++i) acc[i] += (double)(hs[w * 8 + i] - hs[w * 8 + i - 1]);
+            t0 = std::min(t0, hs[w * 8]);
+            t1 = std::max(t1, hs[w * 8 + 5]);
+        }
+        double nw = (double)ctx->nblk * 4;
+        fprintf(stderr, "[mdhip] step_tile cycles/wave: own %.0f stage %.0f barrier %.0f loop %.0f epilogue %.0f | kernel span %lld\n",
+                acc[1] / nw, acc[2] / nw, acc[3] / nw, acc[4] / nw, acc[5] / nw, t1 - t0);
+    }
+    if (fused) {
+        // records -> state arrays, with the last step's pending rescale applied (src/thermostat.jl:43-45)
+        fused_leave(ctx, true);
+        if (nvt) k_set_scale<<<1, 1, 0, st>>>(ctx->scal.p, 1.0);
+    } else if (nvt) {
         // apply the last step's pending rescale (src/thermostat.jl:43-45) so the state the
         // host can download is the reference's
         DevState sd = ctx->dev(ctx->cur);

@@ -213,16 +213,16 @@ def test_position_only_upload_keeps_pending_image_crossings(oracle):
     many particles are across a face when the upload happens; images exact against the oracle."""
     from moleculardynamics.jl_amd import MDDevice
     from tests.util import lj_system
-    n, dt = 2048, 0.002
-    s = lj_system(n, kT=6.0)
+    n, dt = 2048, 0.004
+    s = lj_system(n, kT=8.0)
     pot = oracle.make_pot(0, LJ)
-    ref = oracle.run(s["x"], s["img"], s["v"], s["f"], s["diam"], s["box"], 2.5, pot, dt, 50, nthreads=4)
-    assert np.abs(ref["img"]).sum() > 20           # the run does cross faces
+    ref = oracle.run(s["x"], s["img"], s["v"], s["f"], s["diam"], s["box"], 2.5, pot, dt, 60, nthreads=4)
+    assert np.abs(ref["img"]).sum() > 50           # the run does cross faces (118 crossings)
     with MDDevice(3, n, s["box"], 2.5) as dev:
         dev.set_potential(0, LJ)
         dev.upload(s["x"], s["v"], s["f"], s["img"], s["diam"])
         pending = 0
-        for piece in (7, 9, 11, 23):
+        for piece in (7, 9, 11, 33):
             dev.run(piece, dt)
             x, v, f, im = dev.download()
             dev.upload(x=x)                         # coordinates only: counters stay on the device
