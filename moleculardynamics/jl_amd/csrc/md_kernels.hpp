@@ -1014,12 +1014,18 @@ __global__ void __launch_bounds__(MD_TILE)
                  const int32_t *__restrict__ nmax_tile, const uint32_t *__restrict__ halo, int hcap,
                  const int32_t *__restrict__ halo_count, double dt, double *__restrict__ partials, int nblk_total,
                  Scalars *__restrict__ sc, int step, uint16_t *__restrict__ rows_in, int32_t *__restrict__ nmax_in,
-                 double rin2)
+                 double rin2, long long *__restrict__ stamps = nullptr)
 {
+#define MD_SSTAMP(i)                                                                                   \
+    do {                                                                                               \
+        if (stamps && (threadIdx.x & 63) == 0)                                                         \
+            stamps[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (i)] = (long long)clock64();   \
+    } while (0)
     constexpr int RS = UNIFORM ? 24 : 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ double red[16];
     if (sc->first_viol <= step) return;
+    MD_SSTAMP(0);
     int bid = xcd_remap(blockIdx.x, gridDim.x);
     const double4 *__restrict__ P = s.pos;
     int H = halo_count[bid];
@@ -1046,6 +1052,7 @@ __global__ void __launch_bounds__(MD_TILE)
 #pragma unroll
         for (int c = 0; c < D; ++c) v0[c] = s.v[c][kk];
     }
+    MD_SSTAMP(1);
     // stage the halo: all of a thread's index loads are issued first, then all its gathers, so that the
     // dependent index -> record chain is paid once per 8 records instead of once per record
     for (int h0 = 0; h0 <= H; h0 += 8 * MD_TILE) {
@@ -1089,9 +1096,12 @@ __global__ void __launch_bounds__(MD_TILE)
             }
         }
     }
+    MD_SSTAMP(2);
     __syncthreads();
+    MD_SSTAMP(3);
     double fx = 0.0, fy = 0.0, fz = 0.0, us = 0.0, ws = 0.0;
     tile_pair_loop<D, POT, UNIFORM, WANT_UW, PRUNE>(smem, row4, jn, m, H, pi, pp, rin64, rin2, acc, cin, fx, fy, fz, us, ws);
+    MD_SSTAMP(4);
     if constexpr (PRUNE) tile_prune_tail<D, UNIFORM>(s, sc, H, k, active, lane, wt, pi, rin64, nmax_in, acc, cin);
     double ke = 0.0;
     if (active) {
@@ -1126,6 +1136,8 @@ __global__ void __launch_bounds__(MD_TILE)
             partials[2 * nblk_total + bid] = tw;
         }
     }
+    MD_SSTAMP(5);
+#undef MD_SSTAMP
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1151,8 +1163,13 @@ __global__ void __launch_bounds__(MD_TILE)
 // operations; a stated deviation at the 1-ulp level, inside the trajectory tolerance.
 // ------------------------------------------------------------------------------------------
 struct StepBufs {
-    const double *recA;
-    double *recB;
+    // State records as PLANES of 16-byte pairs: plane 0 = (p.x, p.y), 1 = (p.z, v'.x), 2 = (v'.y, v'.z) [, 3 = (sigma, -)],
+    // element k of plane q at rec[q * rstride + k].  A tile's halo is mostly runs of consecutive slots (cell by
+    // cell), so each of the three gather instructions of the staging reads nearly contiguous memory, and the tile's
+    // own loads and stores are fully coalesced (48-byte AoS records: every instruction strided by 48 bytes).
+    const double2 *recA;
+    double2 *recB;
+    size_t rstride;
     const double *fA[3];
     double *fB[3];
     double4 *posB;
@@ -1173,7 +1190,6 @@ __global__ void __launch_bounds__(MD_TILE)
             stamps[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (i)] = (long long)clock64();   \
     } while (0)
     constexpr int RS = UNIFORM ? 24 : 32;
-    constexpr int RG = UNIFORM ? 6 : 8; // doubles per state record
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ double red[16];
     // (strictly earlier: a violation found by another block of THIS launch must not stop the blocks behind it --
@@ -1196,10 +1212,10 @@ __global__ void __launch_bounds__(MD_TILE)
     const double alpha = sc->scale;
     const double adt = alpha * dt;
     // own record, previous forces, reference positions of the rows in use
-    const double2 *ra = (const double2 *)(sb.recA + (size_t)kk * RG);
-    double2 a0 = ra[0], a1 = ra[1], a2 = ra[2]; // (p.x p.y) (p.z v'.x) (v'.y v'.z)
+    const double2 *RA0 = sb.recA, *RA1 = RA0 + sb.rstride, *RA2 = RA1 + sb.rstride, *RA3 = RA2 + sb.rstride;
+    double2 a0 = RA0[kk], a1 = RA1[kk], a2 = RA2[kk]; // (p.x p.y) (p.z v'.x) (v'.y v'.z)
     double sig_own = pp.sig_u;
-    if constexpr (!UNIFORM) sig_own = ra[3].x;
+    if constexpr (!UNIFORM) sig_own = RA3[kk].x;
     double fprev[3] = {0.0, 0.0, 0.0}, xr[3] = {0.0, 0.0, 0.0};
 #pragma unroll
     for (int c = 0; c < D; ++c) {
@@ -1222,13 +1238,12 @@ __global__ void __launch_bounds__(MD_TILE)
         double2 r0[8], r1[8], r2[8], r3[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const double2 *rb = (const double2 *)(sb.recA + (size_t)(idx[i] & 0x3ffffffu) * RG);
             bool ok = idx[i] != 0xffffffffu;
-            if (!ok) rb = (const double2 *)sb.recA;
-            r0[i] = rb[0];
-            r1[i] = rb[1];
-            r2[i] = rb[2];
-            if constexpr (!UNIFORM) r3[i] = rb[3];
+            size_t j = ok ? (size_t)(idx[i] & 0x3ffffffu) : 0;
+            r0[i] = RA0[j];
+            r1[i] = RA1[j];
+            r2[i] = RA2[j];
+            if constexpr (!UNIFORM) r3[i] = RA3[j];
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -1303,11 +1318,11 @@ __global__ void __launch_bounds__(MD_TILE)
             pn[c] = __builtin_fma(h2, fn[c], xn[c]);
             ke += vp[c] * vp[c];
         }
-        double2 *rb = (double2 *)(sb.recB + (size_t)k * RG);
-        rb[0] = make_double2(pn[0], pn[1]);
-        rb[1] = make_double2(pn[2], vp[0]);
-        rb[2] = make_double2(vp[1], vp[2]);
-        if constexpr (!UNIFORM) rb[3] = make_double2(sig_own, 0.0);
+        double2 *RB = sb.recB;
+        RB[k] = make_double2(pn[0], pn[1]);
+        RB[sb.rstride + k] = make_double2(pn[2], vp[0]);
+        RB[2 * sb.rstride + k] = make_double2(vp[1], vp[2]);
+        if constexpr (!UNIFORM) RB[3 * sb.rstride + k] = make_double2(sig_own, 0.0);
     } else {
         us = 0.0;
         ws = 0.0;
@@ -1330,9 +1345,8 @@ __global__ void __launch_bounds__(MD_TILE)
 
 // state arrays <-> step records (start and end of a fused step loop, and around a list build inside it)
 template <int D, bool UNIFORM>
-__global__ void __launch_bounds__(MD_BLOCK) k_fuse(int n, DevState s, double *__restrict__ rec, double h2)
+__global__ void __launch_bounds__(MD_BLOCK) k_fuse(int n, DevState s, double2 *__restrict__ rec, size_t rstride, double h2)
 {
-    constexpr int RG = UNIFORM ? 6 : 8;
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     double4 p = s.pos[k];
@@ -1342,24 +1356,23 @@ __global__ void __launch_bounds__(MD_BLOCK) k_fuse(int n, DevState s, double *__
         pp3[c] = __builtin_fma(h2, s.f[c][k], pp3[c]);
         v3[c] = s.v[c][k];
     }
-    double2 *rb = (double2 *)(rec + (size_t)k * RG);
-    rb[0] = make_double2(pp3[0], pp3[1]);
-    rb[1] = make_double2(pp3[2], v3[0]);
-    rb[2] = make_double2(v3[1], v3[2]);
-    if constexpr (!UNIFORM) rb[3] = make_double2(p.w, 0.0);
+    rec[k] = make_double2(pp3[0], pp3[1]);
+    rec[rstride + k] = make_double2(pp3[2], v3[0]);
+    rec[2 * rstride + k] = make_double2(v3[1], v3[2]);
+    if constexpr (!UNIFORM) rec[3 * rstride + k] = make_double2(p.w, 0.0);
 }
 
 template <int D, bool UNIFORM>
 __global__ void __launch_bounds__(MD_BLOCK)
-    k_unfuse(int n, DevState s, const double *__restrict__ rec, const Scalars *sc, int apply_scale)
+    k_unfuse(int n, DevState s, const double2 *__restrict__ rec, size_t rstride, const Scalars *sc, int apply_scale)
 {
-    constexpr int RG = UNIFORM ? 6 : 8;
     int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
-    const double *r = rec + (size_t)k * RG;
+    double2 b1 = rec[rstride + k], b2 = rec[2 * rstride + k];
+    const double v3[3] = {b1.y, b2.x, b2.y};
     double scale = apply_scale ? sc->scale : 1.0;
 #pragma unroll
-    for (int c = 0; c < D; ++c) s.v[c][k] = r[3 + c] * scale;
+    for (int c = 0; c < D; ++c) s.v[c][k] = v3[c] * scale;
 }
 
 // ------------------------------------------------------------------------------------------

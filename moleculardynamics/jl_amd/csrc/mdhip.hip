@@ -184,7 +184,7 @@ struct md_ctx {
     int64_t steps_since_prune = 0;
     // fused step loop (k_step_tile): ping-pong state records; `fz_a` = the buffer set that holds the latest complete
     // step: records rec[fz_a], forces sb[cur ^ fz_a].f, positions sb[cur ^ fz_a].pos  (set 0 is the canonical state)
-    DBuf<double> rec[2];
+    DBuf<double2> rec[2];
     int fz_a = 0;
     bool allow_fused = true;
     double d1_rate = 0.0;       // growth per step of the largest displacement since a reference (measured)
@@ -706,7 +706,8 @@ void launch_force_tpu(md_ctx *c, bool want_uw, bool kick, double dt, int step, i
         }                                                                                                           \
         kfn<<<nb, MD_TILE, c->tile_lds, c->stream>>>(n, s, c->pp, rows16, c->maxn, rowmax, c->halo.p, c->hcap,      \
                                                      c->halo_count.p, dt, c->partials.p, nb, c->scal.p, step,       \
-                                                     c->nlist16_in.p, c->nmax_tile_in.p, rin * rin);                \
+                                                     c->nlist16_in.p, c->nmax_tile_in.p, rin * rin,                 \
+                                                     c->dbg_stamps.p);                                              \
     } while (0)
     prof_begin(c);
     if (c->use_tiles) {
@@ -768,7 +769,8 @@ void launch_force_custom(md_ctx *c, int dim, bool want_uw, bool kick, double dt,
         uint16_t *rin = nullptr;
         int32_t *nin = nullptr;
         double rin2 = 0.0;
-        void *args[] = {&n, &s, &c->pp, &l16, &maxn, &nmt, &halo, &hcap, &hc, &dt, &part, &nb, &sc, &step, &rin, &nin, &rin2};
+        long long *stamps = nullptr;
+        void *args[] = {&n, &s, &c->pp, &l16, &maxn, &nmt, &halo, &hcap, &hc, &dt, &part, &nb, &sc, &step, &rin, &nin, &rin2, &stamps};
         HIPCHK(hipModuleLaunchKernel(c->rtc->tile[dim - 2][want_uw][kick], nb, 1, 1, MD_TILE, 1, 1,
                                      (unsigned)c->tile_lds, c->stream, args, nullptr));
     } else {
@@ -887,20 +889,20 @@ void fused_enter(md_ctx *c, double dt)
 {
     int n = (int)c->n;
     const bool uni = fused_uniform(c);
-    const size_t rg = uni ? 6 : 8;
-    for (int w = 0; w < 2; ++w) c->rec[w].ensure((size_t)c->ncap * rg);
+    const size_t planes = uni ? 3 : 4;
+    for (int w = 0; w < 2; ++w) c->rec[w].ensure((size_t)c->ncap * planes);
     DevState s = c->dev(c->cur);
     double h2 = (dt * dt) / 2.0;
     if (c->dim == 3) {
         if (uni)
-            k_fuse<3, true><<<c->nblk, MD_BLOCK, 0, c->stream>>>(n, s, c->rec[0].p, h2);
+            k_fuse<3, true><<<c->nblk, MD_BLOCK, 0, c->stream>>>(n, s, c->rec[0].p, (size_t)c->ncap, h2);
         else
-            k_fuse<3, false><<<c->nblk, MD_BLOCK, 0, c->stream>>>(n, s, c->rec[0].p, h2);
+            k_fuse<3, false><<<c->nblk, MD_BLOCK, 0, c->stream>>>(n, s, c->rec[0].p, (size_t)c->ncap, h2);
     } else {
         if (uni)
-            k_fuse<2, true><<<c->nblk, MD_BLOCK, 0, c->stream>>>(n, s, c->rec[0].p, h2);
+            k_fuse<2, true><<<c->nblk, MD_BLOCK, 0, c->stream>>>(n, s, c->rec[0].p, (size_t)c->ncap, h2);
         else
-            k_fuse<2, false><<<c->nblk, MD_BLOCK, 0, c->stream>>>(n, s, c->rec[0].p, h2);
+            k_fuse<2, false><<<c->nblk, MD_BLOCK, 0, c->stream>>>(n, s, c->rec[0].p, (size_t)c->ncap, h2);
     }
     c->fz_a = 0;
 }
@@ -921,18 +923,18 @@ void fused_leave(md_ctx *c, bool apply_scale)
         }
     }
     DevState s = c->dev(c->cur);
-    const double *rec = c->rec[c->fz_a].p;
+    const double2 *rec = c->rec[c->fz_a].p;
     int ap = apply_scale ? 1 : 0;
     if (c->dim == 3) {
         if (uni)
-            k_unfuse<3, true><<<c->nblk, MD_BLOCK, 0, c->stream>>>(n, s, rec, c->scal.p, ap);
+            k_unfuse<3, true><<<c->nblk, MD_BLOCK, 0, c->stream>>>(n, s, rec, (size_t)c->ncap, c->scal.p, ap);
         else
-            k_unfuse<3, false><<<c->nblk, MD_BLOCK, 0, c->stream>>>(n, s, rec, c->scal.p, ap);
+            k_unfuse<3, false><<<c->nblk, MD_BLOCK, 0, c->stream>>>(n, s, rec, (size_t)c->ncap, c->scal.p, ap);
     } else {
         if (uni)
-            k_unfuse<2, true><<<c->nblk, MD_BLOCK, 0, c->stream>>>(n, s, rec, c->scal.p, ap);
+            k_unfuse<2, true><<<c->nblk, MD_BLOCK, 0, c->stream>>>(n, s, rec, (size_t)c->ncap, c->scal.p, ap);
         else
-            k_unfuse<2, false><<<c->nblk, MD_BLOCK, 0, c->stream>>>(n, s, rec, c->scal.p, ap);
+            k_unfuse<2, false><<<c->nblk, MD_BLOCK, 0, c->stream>>>(n, s, rec, (size_t)c->ncap, c->scal.p, ap);
     }
     c->fz_a = 0;
 }
@@ -961,6 +963,7 @@ void launch_step_tpu(md_ctx *c, bool want_uw, double dt, int step)
     StepBufs sbufs{};
     sbufs.recA = c->rec[a].p;
     sbufs.recB = c->rec[a ^ 1].p;
+    sbufs.rstride = (size_t)c->ncap;
     for (int d = 0; d < 3; ++d) {
         sbufs.fA[d] = A.f[d].p;
         sbufs.fB[d] = B.f[d].p;
@@ -1682,7 +1685,7 @@ int md_run(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, double tau, dou
             }
         }
     }
-    if (fused && ctx->dbg_stamps.p) {
+    if (ctx->dbg_stamps.p && ctx->use_tiles) {
         // MDHIP_STAMPS=1: phase cycle counts of the LAST fused launch, averaged over its waves
         std::vector<long long> hs((size_t)ctx->nblk * 4 * 8);
         HIPCHK(hipMemcpyAsync(hs.data(), ctx->dbg_stamps.p, hs.size() * 8, hipMemcpyDeviceToHost, st));
@@ -1695,7 +1698,7 @@ int md_run(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, double tau, dou
             t1 = std::max(t1, hs[w * 8 + 5]);
         }
         double nw = (double)ctx->nblk * 4;
-        fprintf(stderr, "[mdhip] step_tile cycles/wave: own %.0f stage %.0f barrier %.0f loop %.0f epilogue %.0f | kernel span %lld\n",
+        fprintf(stderr, "[mdhip] %s cycles/wave:", fused ? "step_tile" : "force_tile"); fprintf(stderr, " own %.0f stage %.0f barrier %.0f loop %.0f epilogue %.0f | kernel span %lld\n",
                 acc[1] / nw, acc[2] / nw, acc[3] / nw, acc[4] / nw, acc[5] / nw, t1 - t0);
     }
     if (fused) {
