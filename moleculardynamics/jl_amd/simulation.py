@@ -100,9 +100,9 @@ def run_simulation(state, params, ensemble, total_steps, frequency, pathname, tr
                 vir_acc[0] = vir_acc[1] = 0.0
             else:
                 temperature = 2.0 * K / state.nf
-                total_energy = (U + pot.energy_lrc(n, volume)) / n      # src/simulation.jl:433-437
-                pressure = W / (dim * volume) + params.rho * temperature    # :441-442
-                pressure += pot.pressure_lrc(n, volume)                 # :444
+                total_energy = (U + pot.energy_lrc(n, volume)) / n      # src/simulation.jl:120-124
+                pressure = W / (dim * volume) + params.rho * temperature    # :128-129
+                pressure += pot.pressure_lrc(n, volume)                 # :131
             with open(thermo_file, "a") as io:
                 io.write("%d %.6f %.6f %.6f\n" % (last, total_energy, temperature, pressure))
             state.system.energy_and_forces.energy = U

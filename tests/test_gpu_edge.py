@@ -229,3 +229,38 @@ def test_position_only_upload_keeps_pending_image_crossings(oracle):
         x, v, f, im = dev.download()
     assert np.array_equal(im, ref["img"])
     assert np.abs(x - ref["x"]).max() <= 1e-8
+
+
+def test_wrap_lands_exactly_on_the_box_length(oracle):
+    """wrap_to_box (src/boundary.jl:9-15) turns a tiny NEGATIVE coordinate into x == L exactly
+    (frac = x/L = -8.7e-20, floor = -1, frac + 1 rounds to 1.0, L * 1.0 = L) with image -1 -- a coordinate on the
+    closed end of [0, L] that the cell binning has to clamp.  Deterministic free flight (no pair within the cutoff):
+    powers of two make every product exact.  Particle 0 lands on -2^-60 after step 1 (-> x == L, image -1);
+    particle 1 crosses the upper face between steps 1 and 2 (image +1); particle 2 sits still at x == L from the
+    start, which the reference's wrap (frac = 1.0, floor = 1) turns into x = 0, image +1 at the first step.  Bit-exact x and images against the oracle after step 1; 1e-12 / exact afterwards (the device wraps
+    lazily: one rounding instead of one per step, a stated deviation)."""
+    from moleculardynamics.jl_amd import MDDevice
+    L, dt = 16.0, 2.0 ** -10
+    box = np.full(3, L)
+    x = np.array([[2.0 ** -10, 3.0, 3.0], [L - 1.5 * 2.0 ** -10, 9.0, 9.0], [L, 13.0, 5.0], [8.0, 8.0, 14.0]])
+    v = np.array([[-(1.0 + 2.0 ** -50), 0.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 0.0], [0.0, 0.0, 1.0]])
+    n = 4
+    f0, img0, diam = np.zeros_like(x), np.zeros((n, 3), np.int32), np.ones(n)
+    pot = oracle.make_pot(0, LJ)
+    with MDDevice(3, n, box, 2.5) as d:
+        d.set_potential(0, LJ)
+        d.upload(x, v, f0, img0, diam)
+        for nsteps, exact in ((1, True), (1, False), (5, False)):
+            ref = oracle.run(x, img0, v, f0, diam, box, 2.5, pot, dt, nsteps, use_cells=False)
+            d.run(nsteps, dt)
+            xd, vd, fd, imd = d.download()
+            assert np.array_equal(imd, ref["img"]), (imd, ref["img"])
+            assert np.abs(fd).max() == 0.0 and np.abs(ref["f"]).max() == 0.0        # free flight
+            if exact:
+                assert ref["x"][0, 0] == L and ref["img"][0, 0] == -1               # the oracle does land on L
+                assert np.array_equal(xd, ref["x"])
+            else:
+                assert np.abs(xd - ref["x"]).max() <= 1e-12
+            x, v, img0 = ref["x"], ref["v"], ref["img"]
+            # (the device continues from ITS state: unwrapped coordinates, same physical points)
+    assert tuple(ref["img"][:, 0]) == (-1, 1, 1, 0)

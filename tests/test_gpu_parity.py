@@ -289,6 +289,40 @@ def test_full_size_vs_oracle_cells(oracle, n):
         assert np.array_equal(pairs, oracle.pairs_cells(s["x"], s["box"], 2.5))
 
 
+def test_config4_4m_particles_on_one_gpu(oracle):
+    """BASELINE configs[3]: N = 4,194,304, rho = 0.897 (L = 167.22), NVE -- the whole system on ONE handle (~8 GB):
+    forces / U / W / accepted-pair count against the oracle's linked-cell path, Newton's third law, and 20 NVE steps
+    (fused step loop, prune steps and at least the initial list build at this size) against oracle.run."""
+    from moleculardynamics.jl_amd import MDDevice
+    n, nsteps, dt = 4194304, 20, 0.001
+    s = lj_system(n)
+    assert abs(s["box"][0] - 167.2204) < 1e-3
+    pot = oracle.make_pot(0, LJ)
+    f_ref, u_ref, w_ref, npairs = oracle.forces_cells(s["x"], s["box"], 2.5, pot, s["diam"], nthreads=0)
+    ref = oracle.run(s["x"], s["img"], s["v"], s["f"], s["diam"], s["box"], 2.5, pot, dt, nsteps, nthreads=0)
+    with MDDevice(3, n, s["box"], 2.5) as d:
+        d.set_potential(0, LJ)
+        d.upload(s["x"], s["v"], s["f"], s["img"], s["diam"])
+        u, w = d.compute_forces()
+        _, _, f, _ = d.download()
+        cnt = C.c_int64()
+        d._chk(d._L.md_neighbor_pairs(d._h, None, 0, C.byref(cnt)))
+        assert d.stats()["tiled"] == 1
+        d.upload(s["x"], s["v"], s["f"], s["img"], s["diam"])     # zero forces again: the first half-kick uses them (D7)
+        U, W, K = d.run(nsteps, dt)
+        x, v, f2, img = d.download()
+        st = d.stats()
+    _check_forces(f, f_ref, 1e-11)
+    assert abs(u - u_ref) <= 1e-12 * abs(u_ref) and abs(w - w_ref) <= 1e-12 * abs(w_ref)
+    assert cnt.value == npairs
+    assert np.abs(f.sum(axis=0)).max() <= 1e-9 * np.abs(f).sum()
+    assert np.abs(x - ref["x"]).max() <= 1e-10 and np.abs(v - ref["v"]).max() <= 1e-10
+    assert np.array_equal(img, ref["img"])
+    _check_forces(f2, ref["f"], 1e-10)
+    assert abs(U - ref["U"]) <= 1e-11 * abs(ref["U"]) and abs(K - ref["K"]) <= 1e-12 * abs(ref["K"])
+    assert st["prunes"] >= 1 and st["steps"] == nsteps
+
+
 def test_nve_energy_drift_matches_oracle_262k(oracle):
     """north_star: "energy drift within CPU-reference tolerance".  40 NVE steps at N=262144 on both sides from the
     same start: the total energy changes by the same amount (the drift is the truncated potential's, not the
@@ -341,16 +375,16 @@ def test_run_simulation_readme_example(tmp_path, potname):
     pot = md.LennardJones() if potname == "lj" else md.PseudoHS()
     cutoff = 2.5 if potname == "lj" else 1.5
     dt = 0.001 if potname == "lj" else 0.0005
-    params = md.Parameters(rho, 1000, dt, pot)
+    params = md.Parameters(rho, 1024, dt, pot)
     path = str(tmp_path / potname)
     if potname == "lj":
         state = md.initialize_state(params, path, random_init=True, cutoff=cutoff, rng=np.random.default_rng(7))
     else:
         # pseudo hard spheres must not start overlapping (the reference removes overlaps with Packmol):
         # 1 % jitter on the 1.037-spaced lattice keeps every pair beyond sigma
-        L = (1000 / rho) ** (1.0 / 3.0)
-        x0 = md.lattice_positions(1000, np.full(3, L), 3, np.random.default_rng(7), jitter=0.01)
-        state = md.initialize_state(params, path, cutoff=cutoff, positions=x0, diameters=np.ones(1000), unitcell=L)
+        L = (1024 / rho) ** (1.0 / 3.0)
+        x0 = md.lattice_positions(1024, np.full(3, L), 3, np.random.default_rng(7), jitter=0.01)
+        state = md.initialize_state(params, path, cutoff=cutoff, positions=x0, diameters=np.ones(1024), unitcell=L)
     assert os.path.isfile(os.path.join(path, "init.xyz"))
     state.velocities = md.initialize_velocities(1.4737, np.random.default_rng(8), params.n_particles, 3)
     md.run_simulation(state, params, md.NVT(1.4737, 100.0 * dt), 60, 20, path, thermo_name="thermo_nvt.txt")
@@ -365,7 +399,7 @@ def test_run_simulation_readme_example(tmp_path, potname):
     T = [float(r[2]) for r in rows]
     assert all(0.5 < t < 3.0 for t in T)
     assert os.path.isfile(os.path.join(path, "final.xyz")) and os.path.isfile(os.path.join(path, "trajectory.xyz"))
-    assert state.velocities.shape == (1000, 3) and state.images.dtype == np.int32
+    assert state.velocities.shape == (1024, 3) and state.images.dtype == np.int32
     state.system.device.close()
 
 
@@ -543,3 +577,118 @@ def test_cutoff_decisions_follow_reference_arithmetic(oracle, list_cutoff):
             x, _, f, _ = d.download()
             assert np.array_equal(x, s["x"]), which
             _check_forces(f, f_ref)
+
+
+# ---------------------------------------------------------------- thermo line values (src/simulation.jl:118-134)
+@pytest.mark.parametrize("nvt", [False, True])
+def test_thermo_lines_match_oracle(oracle, tmp_path, nvt):
+    """Every thermo row run_simulation writes -- e = (U + energy_lrc)/N, T, P = W/(d V) + rho T + pressure_lrc
+    (src/simulation.jl:118-134), LennardJones(tail_correction=true) (src/potentials.jl:111-152) -- against the
+    oracle's step loop with the same formulas applied to its raw U, T, W rows: identical text at "%.6f".
+    NVT: the driver's thermostat draws are replayed from a clone of state.rng, segment by segment."""
+    import moleculardynamics.jl_amd as md
+    from moleculardynamics.jl_amd.thermostat import draw_bussi
+    n, dt, freq, total, kT = 1024, 0.001, 20, 45, 1.4737
+    rho = 0.897
+    pot = md.LennardJones(tail_correction=True)
+    params = md.Parameters(rho, n, dt, pot)
+    path = str(tmp_path / ("nvt" if nvt else "nve"))
+    state = md.initialize_state(params, path, random_init=True, cutoff=2.5, rng=np.random.default_rng(7))
+    state.velocities = md.initialize_velocities(kT, np.random.default_rng(8), n, 3)
+    x0, v0 = state.system.positions.copy(), state.velocities.copy()
+    box = np.diag(state.unitcell).copy()
+    volume = float(np.prod(box))
+    state.rng = np.random.default_rng(99)
+    clone = np.random.default_rng(99)
+    ens = md.NVT(kT, 100.0 * dt) if nvt else md.NVE()
+    md.run_simulation(state, params, ens, total, freq, path)
+    state.system.device.close()
+    rows = [ln.split() for ln in open(os.path.join(path, "thermo.txt")).read().splitlines()[1:]]
+    # the oracle's run, thermostat noise in the driver's draw order (one draw_bussi call per segment)
+    kw = {}
+    if nvt:
+        segs = [1, 20, 20, 4]          # output steps 0, 20, 40, then the tail to step 44
+        draws = [draw_bussi(state.nf, clone, k) for k in segs]
+        kw = dict(ensemble=1, tau=100.0 * dt, ktemp=np.full(total, kT), r1=np.concatenate([d[0] for d in draws]),
+                  r2=np.concatenate([d[1] for d in draws]))
+    opot = oracle.make_pot(oracle.POT_LJ, LJ)
+    ref = oracle.run(x0, np.zeros((n, 3), np.int32), v0, np.zeros_like(x0), np.ones(n), box, 2.5, opot, dt, total,
+                     frequency=freq, use_cells=False, **kw)
+    L = oracle.lib()
+    dens = n / volume
+    e_lrc = L.oracle_ener_lrc(2.5, dens, 1.0)          # per particle (src/potentials.jl:111-121, :136-143 multiplies by N)
+    p_lrc = L.oracle_pressure_lrc(2.5, dens, 1.0)
+    assert abs(e_lrc - (-0.48028349255352715)) < 1e-4 and abs(p_lrc - (-0.8604505670240141)) < 1e-4   # SURVEY.md section 4 KATs at rho = 0.897
+    assert len(rows) == len(ref["thermo"]) == 3
+    for row, (step, U, T, W) in zip(rows, ref["thermo"]):
+        e = (U + e_lrc * n) / n
+        P = W / (3 * volume) + rho * T + p_lrc
+        want = ("%d %.6f %.6f %.6f" % (int(step), e, T, P)).split()
+        assert abs(float(row[1]) - e) < 2e-6 and abs(float(row[2]) - T) < 2e-6 and abs(float(row[3]) - P) < 2e-6
+        assert row == want, (row, want)
+    assert abs(e_lrc) > 0.4        # the tail correction really is in the energy column
+
+
+# ---------------------------------------------------------------- BASELINE configs[4] through the PLUGIN path
+POLY_SRC = r"""
+// README.md:89-145 written positionally (SURVEY.md D6): evaluate(pot, r, sigma1, sigma2) with
+// params = {rcut, non_additivity}; integer powers as multiply chains (@fastpow)
+__device__ double upow(double x, int n) { double r = 1.0; while (n) { if (n & 1) r *= x; x *= x; n >>= 1; } return r; }
+__device__ void readme_polydisperse(double r, double sigma1, double sigma2, const double *p, double *u, double *f)
+{
+    double rcut = p[0], non_additivity = p[1];
+    double se = 0.5 * (sigma1 + sigma2);
+    se *= (1.0 - non_additivity * fabs(sigma1 - sigma2));
+    double uij = 0.0, fij = 0.0;
+    if (r < rcut * se) {
+        double term_1 = upow(se / r, 12);
+        double c0 = -28.0 / upow(rcut, 12);
+        double c2 = 48.0 / upow(rcut, 14);
+        double c4 = -21.0 / upow(rcut, 16);
+        double term_2 = c2 * upow(r / se, 2);
+        double term_3 = c4 * upow(r / se, 4);
+        uij = term_1 + c0 + term_2 + term_3;
+        fij = 12.0 * upow(se, 12) / upow(r, 13) - 2.0 * c2 * r / upow(se, 2) - 4.0 * c4 * upow(r, 3) / upow(se, 4);
+    }
+    *u = uij;
+    *f = fij;
+}
+"""
+
+
+@pytest.mark.parametrize("rho,dlo,dhi", [(1.0, 0.6, 1.2), (0.58, 0.73, 1.62)])
+def test_config5_polydisperse_through_the_plugin(oracle, rho, dlo, dhi):
+    """BASELINE configs[4]: N = 1200, 2-D, the README's Polydisperse `evaluate` overload, kT = 0.11 -- run through the
+    Potential PLUGIN (md_set_potential_source: hiprtc compiles k_force_tile<2, POT_CUSTOM, ...> around the user's
+    function), not the built-in kind.  Two diameter sets: U[0.6, 1.2] at rho = 1 (tests/util.py explains why), and
+    SURVEY.md's U[0.73, 1.62] in a box scaled to rho = 0.58 (same area fraction) -- the distribution as surveyed, the
+    box adapted, since at rho = 1 that distribution over-packs (area fraction 1.14).  20 steps against the oracle."""
+    import moleculardynamics.jl_amd as md
+    from moleculardynamics.jl_amd import MDDevice
+    s = poly_system(rho=rho, dlo=dlo, dhi=dhi)
+    cutoff = 1.25 * dhi                  # list_cutoff = 1.25 * sigma_eff,max (SURVEY.md section 8(d))
+    pot = oracle.make_pot(oracle.POT_POLYDISPERSE, [1.25, 0.2])
+    f_ref, u_ref, w_ref, pairs_ref = oracle.forces_brute(s["x"], s["box"], cutoff, pot, s["diam"], want_pairs=True)
+    ref = oracle.run(s["x"], s["img"], s["v"], s["f"], s["diam"], s["box"], cutoff, pot, 0.005, 20, use_cells=False)
+    with MDDevice(2, s["n"], s["box"], cutoff) as d:
+        d.set_potential_source(POLY_SRC, "readme_polydisperse", [1.25, 0.2])
+        d.upload(s["x"], s["v"], s["f"], s["img"], s["diam"])
+        u, w = d.compute_forces()
+        _, _, f, _ = d.download()
+        pairs = d.neighbor_pairs()
+        assert d.stats()["tiled"] == 1           # the tiled kernel of the run-time compiled module, 2-D instantiation
+        assert np.array_equal(pairs, pairs_ref[np.lexsort((pairs_ref[:, 1], pairs_ref[:, 0]))])
+        _check_forces(f, f_ref)
+        assert abs(u - u_ref) <= 1e-12 * abs(u_ref) and abs(w - w_ref) <= 1e-12 * abs(w_ref)
+        d.upload(s["x"], s["v"], s["f"], s["img"], s["diam"])
+        U, W, K = d.run(20, 0.005)
+        x, v, _, img = d.download()
+    assert np.abs(x - ref["x"]).max() <= 1e-10 and np.abs(v - ref["v"]).max() <= 1e-10
+    assert np.array_equal(img, ref["img"])
+    assert abs(U - ref["U"]) <= 1e-11 * abs(ref["U"]) and abs(K - ref["K"]) <= 1e-12 * abs(ref["K"])
+    # and the host-side spelling a user would write
+    hostpot = md.Polydisperse(1.25, 0.2)
+    for r, s1, s2 in [(1.0, 1.0, 1.0), (0.9, 0.73, 1.62), (1.3, 1.2, 0.8)]:
+        uo, fo = oracle.evaluate(pot, r, s1, s2)
+        uh, fh = hostpot.evaluate(r, s1, s2)
+        assert abs(uo - uh) <= 1e-13 * max(1.0, abs(uo)) and abs(fo - fh) <= 1e-13 * max(1.0, abs(fo))
