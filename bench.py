@@ -1,21 +1,29 @@
 #!/usr/bin/env python3
 """bench.py -- particle-steps/s of the device-resident MD step loop on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config 3|4] [--scaling weak|strong]
 
-A "step" is one full velocity-Verlet step (first half-kick + drift, ghost refresh, pair
-forces, second half-kick, thermostat) of every particle.  Workload at N=1: BASELINE.json
-configs[2] -- 1,048,576 monodisperse Lennard-Jones particles, rho = 0.897, r_cut = list
-cutoff = 2.5, dt = 0.001, NVT (Bussi stochastic velocity rescaling, tau = 0.1,
-kT = 1.4737; BASELINE.json calls it "Langevin damping=0.1"), fp64, synthetic
-jittered-lattice start.  Inputs are resident in HBM before the
-timed region starts.
+A "step" is one full velocity-Verlet step (first half-kick + drift, pair forces, second half-kick, thermostat)
+of every particle.
 
-Prints ONE JSON line on rank 0 (see README / DESIGN.md for the field meanings).
+  --config 3 (default)  BASELINE.json configs[2], the configuration the metric is quoted on: 1,048,576 monodisperse
+                        Lennard-Jones particles, rho = 0.897, r_cut = list cutoff = 2.5, dt = 0.001, NVT (Bussi
+                        stochastic velocity rescaling, tau = 0.1, kT = 1.4737; BASELINE.json calls it "Langevin
+                        damping=0.1"), fp64.  With --gpus N > 1: --scaling weak (default; 2^20
+                        particles PER GPU, the global box N cubes long in x) or --scaling strong (the one
+                        2^20-particle cube cut into N slabs).
+  --config 4            BASELINE.json configs[3]: N = 4,194,304, rho = 0.897, NVE, the cube cut into N slabs along x
+                        (strong scaling by construction; N = 1 runs the whole system on one handle).
+
+Synthetic jittered-lattice start; inputs are resident in HBM before the timed region starts.
+Prints ONE JSON line on rank 0 (field meanings: DESIGN.md section 4).
 """
 import argparse
+import ctypes as C
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -27,21 +35,44 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 STEP_BYTES = {"nve": 332.0, "nvt": 380.0}   # algorithmic bytes per particle-step
-# the fused force kernel reads x (24 B) and v (24 B) and writes f (24 B) and v (24 B) per owned
-# particle (uniform diameter; +8 B sigma otherwise): DESIGN.md "kernels"
-KICKDRIFT_BYTES = 160   # R pos 32 + v 24 + f 24 + x1 24, W pos 32 + v 24
-FORCE_KERNEL_BYTES = 96.0
+KICKDRIFT_BYTES = 160           # classic loop: R pos 32 + v 24 + f 24 + x1 24, W pos 32 + v 24
+FORCE_KERNEL_BYTES = 96.0       # classic loop's force kernel: R pos 32 + v 24, W f 24 + v 24
+# ISA-counted budget of the pair loop (scripts/isa_budget.py on k_step_tile<3, LJ, uniform, no energies>):
+# per 8 candidates 138 full-rate fp64 instructions, 4 v_rcp_f64 (quarter rate: 4 slots each), 63 32-bit VALU
+# (half a slot each) = 185.5 fp64-rate issue slots
+VALU_SLOTS_PER_CANDIDATE = 185.5 / 8.0
+FP64_SPEC_SLOTS = 256 * 4 * 2.4e9 / 4.0     # datasheet: 1024 SIMDs, one wave64 fp64 instruction per 4 clocks at 2.4 GHz
+KERNEL_SOURCES = ["md_kernels.hpp", "md_build_tile.hpp", "mdhip.hip"]
+
+
+def kernel_hash():
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "moleculardynamics", "jl_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def measured_traffic():
     """HBM bytes per launch of the dominant kernel from the PMC passes (FETCH_SIZE / WRITE_SIZE collected in
-    separate rocprofv3 --pmc runs of this same command, gfx950 read-side correction applied); the summary
-    lives in profiles/ because counters cannot be collected from inside the benchmark process."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic_k_force_tile.json")) as f:
-            return json.load(f)["traffic_bytes_corrected"]
-    except Exception:
-        return None
+    separate rocprofv3 --pmc runs of this same command, gfx950 read-side correction applied).  Counters cannot be
+    collected from inside the benchmark process, so the number comes from profiles/ -- and only counts when that
+    profile was taken with the kernel sources this run uses (hash of the kernel sources recorded with it);
+    otherwise `traffic` is null and the stale profile is only named."""
+    best = None
+    for name in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+        if name.endswith(".json") and "traffic" in name:
+            try:
+                with open(os.path.join(ROOT, "profiles", name)) as f:
+                    d = json.load(f)
+            except Exception:
+                continue
+            if d.get("kernel_sources_sha256_16") == kernel_hash():
+                return d.get("traffic_bytes_corrected"), {"file": "profiles/" + name, "matches_kernel_sources": True}
+            if best is None:
+                best = {"file": "profiles/" + name, "matches_kernel_sources": False,
+                        "stale_bytes": d.get("traffic_bytes_corrected")}
+    return None, best
 
 
 def parse():
@@ -49,8 +80,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--particles", dest="n", type=int, default=1048576, help="particles per GPU")
-    ap.add_argument("--ensemble", choices=["nvt", "nve"], default="nvt")
+    ap.add_argument("--config", type=int, choices=[3, 4], default=3,
+                    help="3: BASELINE configs[2] (1M NVT, the metric's configuration); 4: configs[3] (4M NVE, slabs)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                    help="config 3 with --gpus > 1: weak (default, 2^20 particles per GPU) or strong (2^20 in total)")
+    ap.add_argument("--particles", dest="n", type=int, default=None, help="override the particle count (per GPU if weak)")
+    ap.add_argument("--ensemble", choices=["nvt", "nve"], default=None)
     ap.add_argument("--skin", type=float, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=40)
@@ -69,10 +104,9 @@ def make_inputs(n, seed_shift=0):
                 diam=np.ones(n), kT=kT, rho=rho)
 
 
-def host_cores(omp_max):
-    """Threads the CPU baseline may use: the cores this process is actually allowed (affinity and
-    cgroup quota), capped at 16 -- a one-GPU box's CPU share."""
-    n = omp_max
+def host_cores():
+    """Cores this process may actually use (affinity and cgroup quota) -- printed, not capped."""
+    n = os.cpu_count() or 1
     try:
         n = min(n, len(os.sched_getaffinity(0)))
     except Exception:
@@ -83,25 +117,64 @@ def host_cores(omp_max):
             n = min(n, max(1, int(float(q) / float(p))))
     except Exception:
         pass
-    return max(1, min(n, 16))
+    return max(1, n)
+
+
+def native_oracle():
+    """The oracle built -march=native ON THIS machine for the timing leg; falls back to the
+    portable build that travelled with the snapshot."""
+    from oracle import oracle as orc
+    try:
+        subprocess.check_call(["make", "-s", "-B", "-C", os.path.join(ROOT, "oracle"), "native"], stdout=subprocess.DEVNULL,
+                              stderr=subprocess.DEVNULL)
+        so = os.path.join(ROOT, "oracle", "libmdoracle_native.so")
+        if os.path.exists(so):
+            orc._SO = so
+            orc._lib = None
+            return orc, "-O3 -march=native -ffp-contract=off -fopenmp"
+    except Exception:
+        pass
+    return orc, "-O3 -mavx2 -mfma -ffp-contract=off -fopenmp (portable build: native build failed)"
 
 
 def cpu_baseline(inp, steps, dt):
-    """The oracle's linked-cell path (OpenMP, privatised force buffers) timed on the host cores,
-    on a bounded sample: the same 1M-particle workload for `steps` steps (NVE loop; the Bussi
-    rescale is O(N) noise next to the pair loop)."""
-    from oracle import oracle as orc
+    """The oracle's linked-cell path (OpenMP, privatised force buffers) timed on the host cores, on a bounded sample:
+    the same workload for `steps` steps (NVE loop; the Bussi rescale is O(N) noise next to the pair loop), on all the
+    cores this process may use and on ONE thread (the only mode in which the reference itself is sound)."""
+    orc, flags = native_oracle()
     pot = orc.make_pot(orc.POT_LJ, [1.0, 1.0, 2.5])
-    nthreads = host_cores(orc.max_threads())
+    cores = host_cores()
+    nthreads = min(cores, orc.max_threads()) if orc.max_threads() > 0 else cores
     w = make_inputs(4096)  # spin up the OpenMP pool / page in the library, untimed
     orc.forces_cells(w["x"], w["box"], 2.5, pot, w["diam"], nthreads=nthreads)
     t0 = time.perf_counter()
     orc.run(inp["x"], inp["img"], inp["v"], inp["f"], inp["diam"], inp["box"], 2.5, pot, dt, steps, use_cells=True,
             nthreads=nthreads)
     el = time.perf_counter() - t0
-    return dict(value=inp["n"] * steps / el, unit="particle-steps/s", cores=nthreads, kind="port",
-                sample=f"{steps} steps of the same N={inp['n']} workload (NVE loop), oracle linked cells + OpenMP, "
-                       f"{el:.1f} s wall")
+    many = dict(value=inp["n"] * steps / el, unit="particle-steps/s", cores=nthreads, kind="port",
+                sample=f"{steps} steps of the same N={inp['n']} workload (NVE loop), oracle linked cells + OpenMP "
+                       f"({flags}), {el:.1f} s wall; host reports {os.cpu_count()} CPUs, {cores} usable by this process")
+    s1 = max(2, min(steps, 6))
+    t0 = time.perf_counter()
+    orc.run(inp["x"], inp["img"], inp["v"], inp["f"], inp["diam"], inp["box"], 2.5, pot, dt, s1, use_cells=True, nthreads=1)
+    el1 = time.perf_counter() - t0
+    one = dict(value=inp["n"] * s1 / el1, unit="particle-steps/s", cores=1, kind="port",
+               sample=f"{s1} steps of the same workload on one thread, {el1:.1f} s wall")
+    return many, one
+
+
+def fp64_probe(device):
+    """Measured fp64 vector rate of this GPU (wave64 instruction slots per second): csrc/md_probe.hip."""
+    so = os.path.join(ROOT, "moleculardynamics", "jl_amd", "csrc", "libmdprobe.so")
+    try:
+        L = C.CDLL(so)
+        L.md_probe_fp64_rate.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        slots, gf = C.c_double(), C.c_double()
+        if L.md_probe_fp64_rate(int(device), C.byref(slots), C.byref(gf)) == 0:
+            return slots.value, gf.value
+    except Exception:
+        pass
+    return None, None
 
 
 def main():
@@ -111,6 +184,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
+    cfg4 = a.config == 4
+    ensemble = a.ensemble or ("nve" if cfg4 else "nvt")
+    scaling = "strong" if cfg4 else (a.scaling or "weak")
+    n_arg = a.n if a.n is not None else (4194304 if cfg4 else 1048576)
     # MDHIP_BENCH_DOMAIN=1: run the slab-decomposition code path with a single rank (its two x-neighbours are
     # itself; RCCL carries the self-exchange) -- measures the multi-GPU path's per-GPU cost on a one-GPU box
     use_domain = world > 1 or os.environ.get("MDHIP_BENCH_DOMAIN", "0") == "1"
@@ -135,11 +212,13 @@ def main():
     from moleculardynamics.jl_amd.thermostat import draw_bussi
 
     dt, tau = 0.001, 0.1
-    nvt = a.ensemble == "nvt"
-    inp = make_inputs(a.n, seed_shift=rank)
+    nvt = ensemble == "nvt"
+    loop = "single handle"
     if not use_domain:
-        nf = 3.0 * (a.n - 1.0)
-        dev = MDDevice(3, a.n, inp["box"], 2.5, device_id=local_rank)
+        inp = make_inputs(n_arg)
+        n_local, total_particles = n_arg, n_arg
+        nf = 3.0 * (n_arg - 1.0)
+        dev = MDDevice(3, n_arg, inp["box"], 2.5, device_id=local_rank)
         dev.set_potential(_lib.MD_POT_LJ, [1.0, 1.0, 2.5])
         if a.skin is not None:
             dev.set_skin(a.skin)
@@ -155,15 +234,31 @@ def main():
                 return dev.run(nsteps, dt, _lib.MD_NVT, tau, nf, kt, r1, r2, thermo=thermo)
             return dev.run(nsteps, dt, _lib.MD_NVE, thermo=thermo)
     else:
-        # weak scaling: every rank owns one cube of a.n particles; the global box is `world` cubes long in
-        # x, cut into slabs (1-D spatial decomposition), halo coordinates exchanged every step
-        from moleculardynamics.jl_amd.domain import DomainDevice, Exchanger
+        from moleculardynamics.jl_amd.domain import DomainDevice, Exchanger, owner_of
         ex = Exchanger(device_index=local_rank)
-        L1 = float(inp["box"][0])
-        gbox = np.array([world * L1, L1, L1])
-        n_global = a.n * world
-        nf = 3.0 * (n_global - 1.0)
-        dev = DomainDevice(3, n_global, gbox, 2.5, ex, device_id=local_rank, n_cap=int(1.3 * a.n) + 8192)
+        if scaling == "weak":
+            # every rank owns one cube of n_arg particles; the global box is `world` cubes long in x
+            inp = make_inputs(n_arg, seed_shift=rank)
+            L1 = float(inp["box"][0])
+            gbox = np.array([world * L1, L1, L1])
+            total_particles = n_arg * world
+            xg = inp["x"].copy()
+            xg[:, 0] += rank * L1
+            ids = (rank * n_arg + np.arange(n_arg)).astype(np.int32)
+            loc = dict(x=xg, v=inp["v"], f=inp["f"], img=inp["img"], diam=inp["diam"])
+        else:
+            # strong: ONE cube of n_arg particles (every rank generates the same global system from the same
+            # seeds and keeps the particles of its slab); ids are the global indices
+            inp = make_inputs(n_arg)
+            gbox = inp["box"].copy()
+            total_particles = n_arg
+            mine = np.nonzero(owner_of(inp["x"][:, 0], float(gbox[0]), world) == rank)[0]
+            ids = mine.astype(np.int32)
+            loc = dict(x=inp["x"][mine], v=inp["v"][mine], f=inp["f"][mine], img=inp["img"][mine], diam=inp["diam"][mine])
+        n_local = int(ids.size)
+        nf = 3.0 * (total_particles - 1.0)
+        n_cap = int(1.3 * max(n_local, total_particles // world)) + 8192
+        dev = DomainDevice(3, total_particles, gbox, 2.5, ex, device_id=local_rank, n_cap=n_cap)
         dev.set_potential(_lib.MD_POT_LJ, [1.0, 1.0, 2.5])
         # step loop (MDHIP_DOM_LOOP): "native" = windows of steps inside the library, RCCL issued by the library
         # (default with one GPU per rank); "async" = the same scheme driven from Python through
@@ -172,7 +267,6 @@ def main():
         if os.environ.get("MDHIP_DOM_SYNC", "0") == "1":
             loop = "sync"
         stepper = {"sync": dev.run, "async": dev.run_async, "native": dev.run_native}[loop]
-        sync_loop = loop == "sync"
 
         if a.skin is not None:
             dev.set_skin(a.skin)
@@ -192,11 +286,8 @@ def main():
             if int(tok.item()) == 0:
                 loop = "async"
                 stepper = dev.run_async
-        xg = inp["x"].copy()
-        xg[:, 0] += rank * L1
-        ids = (rank * a.n + np.arange(a.n)).astype(np.int32)
         dev.set_uniform(True, 1.0)
-        dev.upload_local(ids, xg, inp["v"], inp["f"], inp["img"], inp["diam"])
+        dev.upload_local(ids, loc["x"], loc["v"], loc["f"], loc["img"], loc["diam"])
         rng = np.random.default_rng(4242)      # the same stream on every rank: identical thermostat noise
 
         def run(nsteps, thermo=False):
@@ -216,9 +307,9 @@ def main():
     run(a.equil)           # melt the lattice so the timed region sees a liquid, untimed
     run(a.warmup)
     st0 = dev.stats()
-    # kernel durations: HIP events on the handle's stream around every 7th force and kick-drift launch of the
-    # timed region (every launch would cost ~8 % of the throughput being measured; 7 is coprime to the prune
-    # cadence, so ordinary and prune steps are sampled in proportion)
+    # kernel durations: HIP events on the handle's stream around every 7th step-kernel launch of the timed region
+    # (every launch would cost ~8 % of the throughput being measured; 7 is coprime to the prune cadence, so ordinary
+    # and prune steps are sampled in proportion)
     dev.profile(0 if os.environ.get("MDHIP_BENCH_NOPROF", "0") == "1" else 7)
     barrier()
     t0 = time.perf_counter()
@@ -233,14 +324,42 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
 
-    total_particles = a.n * world
     value = total_particles * a.steps / el
-    n_for_thermo = total_particles
     launches = max(1, st1["force_launches"])
     kern_ms = st1["force_ms"] / launches
-    achieved = (FORCE_KERNEL_BYTES * a.n) / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-    step_bytes = STEP_BYTES[a.ensemble]
-    traffic = measured_traffic() if (not use_domain and a.n == 1048576) else None
+    fused = bool(st1.get("fused", 0))
+    step_bytes = STEP_BYTES[ensemble]
+    # the dominant kernel: fused loop -> k_step_tile IS the step (all of SURVEY.md section 8(d)'s per-particle-step
+    # bytes pass through it); classic loop -> k_force_tile with its own 96 B per particle
+    per_particle = step_bytes if fused else FORCE_KERNEL_BYTES
+    achieved = (per_particle * n_local) / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
+    traffic, traffic_src = (None, None)
+    if not use_domain and n_arg == 1048576:
+        traffic, traffic_src = measured_traffic()
+    # fp64-VALU co-roofline (SURVEY.md section 8(d) asks for both): issue slots the pair loop needs for the row
+    # entries it walks, against the measured v_fma_f64 rate of this GPU
+    pr = st1.get("prune_launches_timed", 0)
+    walked = None
+    if st1.get("walked_inner", 0) > 0 or st1.get("walked_outer", 0) > 0:
+        w_in = st1["walked_inner"] if st1["walked_inner"] > 0 else st1["walked_outer"]
+        walked = (w_in * (launches - pr) + st1["walked_outer"] * pr) / launches
+    probe_slots, probe_gf = fp64_probe(local_rank) if rank == 0 else (None, None)
+    valu = None
+    if walked and kern_ms > 0:
+        need = walked / 64.0 * VALU_SLOTS_PER_CANDIDATE          # wave64 issue slots per launch
+        ach = need / (kern_ms * 1e-3)
+        valu = {"bound": "fp64 VALU issue", "slots_per_candidate": VALU_SLOTS_PER_CANDIDATE,
+                "candidates_walked_per_particle": walked / n_local, "achieved_slots_per_s": ach,
+                "peak_slots_per_s_measured": probe_slots, "peak_slots_per_s_spec": FP64_SPEC_SLOTS,
+                "frac_of_measured": (ach / probe_slots) if probe_slots else None, "frac_of_spec": ach / FP64_SPEC_SLOTS,
+                "probe_gflops_fp64_fma": probe_gf,
+                "note": "pair loop only (ISA-counted, scripts/isa_budget.py); staging, epilogue and the padded lanes of "
+                        "short rows are not counted as useful work"}
+    workload = (f"BASELINE configs[3]: N={total_particles} LJ 3D rho=0.897 r_cut=2.5 dt=0.001 NVE, cube cut into "
+                f"{world} slab(s) along x" if cfg4 else
+                f"BASELINE configs[2]: N={n_arg} monodisperse LJ 3D rho=0.897 r_cut=2.5 dt=0.001 "
+                f"{'NVT Bussi tau=0.1 kT=1.4737' if nvt else 'NVE'}"
+                + (", per GPU" if scaling == "weak" else f", {total_particles} particles in total"))
     out = {
         "metric": "particle-steps/sec + achieved HBM GB/s, 1M LJ particles rho=0.897, 1/2/4/8 GPUs",
         "value": value,
@@ -250,17 +369,17 @@ def main():
         "warmup": a.warmup,
         "ms_per_step": el * 1e3 / a.steps,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": scaling,
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": f"BASELINE configs[2]: N={a.n} monodisperse LJ 3D rho=0.897 r_cut=2.5 dt=0.001 "
-                        f"{'NVT Bussi tau=0.1 kT=1.4737' if nvt else 'NVE'}, per GPU",
-            "particles_per_gpu": a.n,
+            "workload": workload,
+            "particles_per_gpu": n_local if scaling == "weak" else total_particles / world,
             "parallelism": "1 GPU" if not use_domain else f"{world}-way 1-D slab decomposition along x, halo exchange every "
                                                             f"step over torch.distributed ({dist.get_backend()}), "
                                                             f"step loop: {loop}",
+            "step_loop": "fused (k_step_tile: one launch per step + k_finalize)" if fused else "classic (k_kickdrift, k_force_tile, k_finalize)",
             "skin": a.skin if a.skin is not None else (0.6 if (not use_domain or st1["prunes"] > 0) else 0.4),
             "rebuilds_in_timed_region": st1["rebuilds"] - st0["rebuilds"],
             "global_particles": total_particles,
@@ -268,6 +387,9 @@ def main():
             "tiled_force_kernel": bool(st1["tiled"]),
             "prunes_in_timed_region": st1["prunes"] - st0["prunes"],
             "max_tile_halo": st1["max_halo"],
+            # the reference accumulates U and W every step; here they are formed on reporting steps only (identical
+            # outputs at `frequency` cadence).  The energy-reporting variant of the kernel is ~25 % slower.
+            "energies_every_step": False,
         },
         "roofline": {
             "bound": "hbm",
@@ -275,34 +397,43 @@ def main():
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS,
+            # measured HBM/IC bytes per launch from the rocprofv3 PMC passes in profiles/ -- only when that profile was
+            # taken with these kernel sources, null otherwise
             "traffic": traffic,
-            # the same launch seen from the memory side: measured HBM/IC bytes (rocprofv3 PMC, profiles/) over the
-            # live kernel duration -- what the rows and halo lists add on top of the algorithmic bytes
+            "traffic_source": traffic_src,
             "traffic_GBps": (traffic / (kern_ms * 1e-3) / 1e9) if (traffic and kern_ms > 0) else None,
-            "kernel": "k_force_tile (pair forces + second half-kick + KE partials; average over ordinary and prune steps)",
+            "kernel": ("k_step_tile (drift folded into the halo staging, pair forces, both half-kicks, KE partials)" if fused
+                       else "k_force_tile (pair forces + second half-kick + KE partials)") + "; average over ordinary and prune steps",
             "kernel_ms": kern_ms,
             "kernel_launches": launches,
-            "bytes_per_launch": FORCE_KERNEL_BYTES * a.n,
+            "prune_launches": pr,
+            "algorithmic_bytes_per_particle": per_particle,
+            "bytes_per_launch": per_particle * n_local,
+            "kernel_sources_sha256_16": kernel_hash(),
         },
-        # the stream kernel of the step (pending rescale + half-kick + drift + displacement check): HBM-bound
+        "valu_roofline": valu,
+        # the classic loop's stream kernel (pending rescale + half-kick + drift + displacement check): HBM-bound
         "kickdrift_roofline": {
-            "bound": "hbm", "bytes_per_launch": KICKDRIFT_BYTES * a.n,
+            "bound": "hbm", "bytes_per_launch": KICKDRIFT_BYTES * n_local,
             "kernel_ms": (st1["kickdrift_ms"] / max(1, st1["kickdrift_launches"])),
-            "achieved": (KICKDRIFT_BYTES * a.n) / max(1e-12, st1["kickdrift_ms"] / max(1, st1["kickdrift_launches"]) * 1e-3) / 1e9,
+            "achieved": (KICKDRIFT_BYTES * n_local) / max(1e-12, st1["kickdrift_ms"] / max(1, st1["kickdrift_launches"]) * 1e-3) / 1e9,
             "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": (KICKDRIFT_BYTES * a.n) / max(1e-12, st1["kickdrift_ms"] / max(1, st1["kickdrift_launches"]) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "frac": (KICKDRIFT_BYTES * n_local) / max(1e-12, st1["kickdrift_ms"] / max(1, st1["kickdrift_launches"]) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
         } if st1["kickdrift_launches"] > 0 else None,
         "step_roofline": {
             "algorithmic_bytes_per_particle_step": step_bytes,
             "achieved_GBps": value / world * step_bytes / 1e9,
             "frac_of_8TBps": value / world * step_bytes / 1e9 / HBM_PEAK_GBPS,
         },
-        "thermo_last_step": {"U_per_particle": uwk[0] / n_for_thermo, "T": 2.0 * uwk[2] / nf, "W": uwk[1]},
+        "thermo_last_step": {"U_per_particle": uwk[0] / total_particles, "T": 2.0 * uwk[2] / nf, "W": uwk[1]},
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(inp, a.cpu_steps, dt)
+        many, one = cpu_baseline(inp, a.cpu_steps if n_arg <= 1048576 else max(4, a.cpu_steps // 4), dt)
+        out["cpu_baseline"] = many
+        out["cpu_baseline_1thread"] = one
     elif rank == 0:
         out["cpu_baseline"] = None
+        out["cpu_baseline_1thread"] = None
     dev.close()
     if rank == 0:
         print(json.dumps(out))

@@ -151,6 +151,11 @@ typedef struct {
     int64_t prunes;         /* row prunes (inner-list refreshes) since create */
     int64_t kickdrift_launches; /* kick-drift kernel launches timed since md_profile(ctx,1) */
     double kickdrift_ms;        /* their summed duration */
+    int64_t fused;          /* 1: the last md_run used the fused step kernel (one launch per step), 0: the classic
+                               kick-drift / force sequence */
+    int64_t walked_outer;   /* row entries one launch over the OUTER rows walks (wave-padded, summed over particles) */
+    int64_t walked_inner;   /* ... over the current INNER rows (0: none valid): the pair evaluations an ordinary step issues */
+    int64_t prune_launches_timed; /* how many of the timed force/step launches were prune steps */
 } md_stats;
 /* enable = 0: off; 1: HIP events around every force and kick-drift launch; k > 1: around every k-th launch of each
  * (an event record costs a few microseconds of device time: sampling keeps a timed run honest) */

@@ -31,7 +31,8 @@ class MdStats(C.Structure):
     _fields_ = [("steps", C.c_int64), ("rebuilds", C.c_int64), ("violations", C.c_int64), ("n_ghost", C.c_int64),
                 ("max_neighbors", C.c_int64), ("avg_neighbors", C.c_double), ("force_launches", C.c_int64),
                 ("force_ms", C.c_double), ("max_halo", C.c_int64), ("tiled", C.c_int64), ("prunes", C.c_int64),
-                ("kickdrift_launches", C.c_int64), ("kickdrift_ms", C.c_double)]
+                ("kickdrift_launches", C.c_int64), ("kickdrift_ms", C.c_double), ("fused", C.c_int64),
+                ("walked_outer", C.c_int64), ("walked_inner", C.c_int64), ("prune_launches_timed", C.c_int64)]
 
 
 class MdhipError(RuntimeError):

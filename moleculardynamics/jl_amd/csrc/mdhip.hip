@@ -205,6 +205,8 @@ struct md_ctx {
     std::vector<int> prof_tag;          // 0: force kernel, 1: kick-drift kernel
     double prof_kd_ms_acc = 0.0;
     int64_t prof_kd_launch_acc = 0;
+    int64_t prof_prune_acc = 0;   // timed force/step launches that were prune steps
+    bool last_run_fused = false;
 
     std::string err;
 
@@ -710,6 +712,7 @@ void launch_force_tpu(md_ctx *c, bool want_uw, bool kick, double dt, int step, i
                                                      c->dbg_stamps.p);                                              \
     } while (0)
     prof_begin(c);
+    if (prune_step && c->prof_open) c->prof_prune_acc++;
     if (c->use_tiles) {
         if (prune_step) {
             if (want_uw)
@@ -984,6 +987,7 @@ void launch_step_tpu(md_ctx *c, bool want_uw, double dt, int step)
                                                      c->nmax_tile_in.p, rin * rin, c->dbg_stamps.p);                \
     } while (0)
     prof_begin(c);
+    if (prune_step && c->prof_open) c->prof_prune_acc++;
     if (prune_step) {
         if (want_uw)
             LS(true, true);
@@ -1473,6 +1477,7 @@ int md_run(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, double tau, dou
     // The fused loop (k_step_tile: one launch per step) whenever the tiled rows exist; the
     // classic three-kernel sequence otherwise (slab handles, user potentials, rows that do not fit LDS, skin 0).
     bool fused = ctx->skin > 0.0 && fused_available(ctx);
+    ctx->last_run_fused = fused;
     if (fused) fused_enter(ctx, dt);
     auto step_part = [&](int t) {
         if (!fused) {
@@ -1926,6 +1931,7 @@ int md_profile(md_ctx *ctx, int enable)
         ctx->prof_launch_acc = 0;
         ctx->prof_kd_ms_acc = 0.0;
         ctx->prof_kd_launch_acc = 0;
+        ctx->prof_prune_acc = 0;
     }
     API_END
 }
@@ -1956,6 +1962,21 @@ int md_get_stats(md_ctx *ctx, md_stats *out)
     out->force_ms = ctx->prof_ms_acc;
     out->kickdrift_launches = ctx->prof_kd_launch_acc;
     out->kickdrift_ms = ctx->prof_kd_ms_acc;
+    out->fused = ctx->last_run_fused ? 1 : 0;
+    out->walked_outer = out->walked_inner = 0;
+    if (ctx->list_valid) {
+        const int64_t nw = (ctx->n + 63) / 64;
+        std::vector<int32_t> h((size_t)nw);
+        HIPCHK(hipMemcpyAsync(h.data(), ctx->nmax_tile.p, sizeof(int32_t) * nw, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        for (int32_t v : h) out->walked_outer += 64 * (int64_t)v;
+        if (ctx->inner_valid) {
+            HIPCHK(hipMemcpyAsync(h.data(), ctx->nmax_tile_in.p, sizeof(int32_t) * nw, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            for (int32_t v : h) out->walked_inner += 64 * (int64_t)v;
+        }
+    }
+    out->prune_launches_timed = ctx->prof_prune_acc;
     API_END
 }
 
