@@ -140,6 +140,45 @@ __device__ __forceinline__ int tile_sweep_emit(const unsigned long long *mask, c
     return cnt;
 }
 
+#define MD_BBMAX 1024    // cells of the tile's bounding box (owned cells dilated by one), local numbering
+#define MD_ROWPITCH 132  // LDS row buffer of the emit phase: 256 rows x 132 entries x 2 bytes, over the dead phase-1 arrays
+#define MD_BT_POOL 68864
+
+// Walks the set bits of the per-cell hit masks and appends the hits to an LDS row as STAGED indices (the copy-out
+// translates them to halo offsets with independent, pipelined lookups -- a lookup inside this walk would put one
+// dependent LDS round trip on every trip of a divergent loop).  Two bits per trip.  Entries beyond the row buffer's
+// pitch (rows of more than MD_ROWPITCH entries: rare) go straight to global memory, translated here.
+__device__ __forceinline__ int tile_sweep_emit_lds(const unsigned long long *mask, const int *qstart,
+                                                   const uint16_t *newidx, uint16_t *row, uint16_t *grow, int lane,
+                                                   int maxn, int cnt0, int rs)
+{
+    int cnt = cnt0;
+#pragma unroll
+    for (int ci = 0; ci < MD_HALF_CELLS; ++ci) {
+        unsigned long long mk = mask[ci];
+        const int qs = qstart[ci];
+        while (mk) {
+            int b1 = __ffsll((long long)mk) - 1;
+            unsigned long long m1 = mk & (mk - 1ull);
+            int b2 = __ffsll((long long)m1) - 1; // (-1 when m1 == 0: not stored)
+            mk = m1 & (m1 - 1ull);
+            if (cnt + 1 < MD_ROWPITCH) {
+                row[cnt] = (uint16_t)(qs + b1);
+                if (m1) row[cnt + 1] = (uint16_t)(qs + b2);
+            } else {
+                if (cnt < MD_ROWPITCH)
+                    row[cnt] = (uint16_t)(qs + b1);
+                else if (cnt < maxn)
+                    grow[row_off(cnt, lane)] = (uint16_t)((unsigned)newidx[qs + b1] * (unsigned)rs);
+                if (m1 && cnt + 1 < maxn) grow[row_off(cnt + 1, lane)] = (uint16_t)((unsigned)newidx[qs + b2] * (unsigned)rs);
+            }
+            cnt += m1 ? 2 : 1;
+        }
+    }
+    return cnt;
+}
+
+
 template <int D>
 __global__ void __launch_bounds__(MD_BT_THREADS)
     k_build_tile(int n, DevState s, BoxGrid g, float rl2f, const int32_t *__restrict__ cell_start,
@@ -152,17 +191,23 @@ __global__ void __launch_bounds__(MD_BT_THREADS)
         if (stamps && threadIdx.x == 0) stamps[(size_t)blockIdx.x * 10 + (i)] = (long long)clock64(); \
     } while (0)
     MD_STAMP(0);
-    __shared__ __attribute__((aligned(16))) float px[MD_SCAP], py[MD_SCAP], pz[MD_SCAP];
+    // phase-1 arrays carved out of one pool; phase 2 (emit) reuses the whole pool as the row buffer
+    __shared__ __attribute__((aligned(16))) unsigned char pool[MD_BT_POOL];
+    float *px = (float *)pool, *py = px + MD_SCAP, *pz = py + MD_SCAP;                    // 43008 bytes
+    unsigned long long *refmask = (unsigned long long *)(pool + 43008);                   // per unique cell: which of its (<= 64) staged particles some row references
+    int *ucell = (int *)(pool + 51200);                                                   // MD_NCMAX
+    int *coff = (int *)(pool + 55296);                                                    // MD_NCMAX + 2
+    int *lcell = (int *)(pool + 59408);                                                   // bounding-box cell (local numbering) -> global cell id, -1: not needed / empty
+    uint16_t *ctab = (uint16_t *)(pool + 63504);                                          // (owned cell ci, offset nb) -> index in ucell[] (0xffff: empty)
+    uint16_t *lmap = (uint16_t *)(pool + 65552);                                          // bounding-box cell -> index in ucell[]
+    uint16_t *blk2u = (uint16_t *)(pool + 67600);                                         // staged slot 32 t -> its unique cell
+    unsigned char *ccnt = (unsigned char *)(pool + 67840);                                // real (unpadded) population of unique cell u (<= 64)
     __shared__ uint16_t newidx[MD_SCAP];
-    __shared__ unsigned long long refmask[MD_NCMAX]; // per unique cell: which of its (<= 64) staged particles some row references
-    __shared__ int ccell[MD_NCMAX], ucell[MD_NCMAX], coff[MD_NCMAX + 2];
-    __shared__ unsigned char ccnt[MD_NCMAX]; // real (unpadded) population of unique cell u (<= 64)
-    __shared__ int ncand[MD_NCMAX];           // neighbour cell of candidate t = (owned cell ci, offset nb), unsorted
-    __shared__ uint16_t ctab[MD_NCMAX];       // its index in ucell[] (0xffff: empty): shared by all lanes of cell ci
-    __shared__ int cntA[MD_TILE];
-    __shared__ int sh_misc[4];
+    __shared__ int cntA[MD_TILE], cntB[MD_TILE];
+    __shared__ int sh_misc[16];
     __shared__ int sh_scan[16];
     __shared__ int sh_ne[MD_NEMAX];
+    __shared__ int sh_ne_e[MD_NEMAX][3];
 
     const int tile = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -184,89 +229,98 @@ __global__ void __launch_bounds__(MD_BT_THREADS)
     if (tid == 0) sh_misc[0] = mycell; // first particle's cell
     const int last_active = min(n - 1, tile * MD_TILE + MD_TILE - 1) - tile * MD_TILE;
     if (tid == last_active) sh_misc[1] = mycell;
-    if (tid == 0) sh_misc[2] = 0;
+    if (tid == 0) {
+        sh_misc[2] = 0;
+        sh_misc[4] = sh_misc[5] = sh_misc[6] = 0x7fffffff; // bounding box of the owned cells (extended coordinates)
+        sh_misc[7] = sh_misc[8] = sh_misc[9] = -1;
+    }
     for (int i = tid; i < MD_NCMAX; i += MD_BT_THREADS) refmask[i] = 0ull;
+    for (int i = tid; i < MD_BBMAX; i += MD_BT_THREADS) lcell[i] = -1;
     __syncthreads();
     const int c_first = sh_misc[0], c_last = sh_misc[1];
     const int R = c_last - c_first + 1; // index slots spanned (includes unused brick slots)
-    // 1a. the non-empty owned cells of the range (order irrelevant: sorted below)
+    // 1a. the non-empty owned cells of the range, their coordinates and bounding box
     for (int ci = tid; ci < R; ci += MD_BT_THREADS) {
         int cell = c_first + ci;
         if (cell_end[cell] > cell_start[cell]) {
             int pos = atomicAdd(&sh_misc[2], 1);
-            if (pos < MD_NEMAX) sh_ne[pos] = cell;
+            if (pos < MD_NEMAX) {
+                int e[3];
+                ext_decode(cell, g, e);
+                sh_ne[pos] = cell;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    sh_ne_e[pos][c] = e[c];
+                    atomicMin(&sh_misc[4 + c], e[c]);
+                    atomicMax(&sh_misc[7 + c], e[c]);
+                }
+            }
         }
     }
     __syncthreads();
     const int nne = sh_misc[2];
     bool bad = (nne > MD_NEMAX) || (nne * NNB > MD_NCMAX);
-    int M = 64; // sort size: next power of two >= nne*NNB
-    while (M < nne * NNB && M < MD_NCMAX) M <<= 1;
-    // 1b. their neighbour cells
-    for (int t = tid; t < M; t += MD_BT_THREADS) {
-        int v = MD_INF_CELL;
-        if (!bad && t < nne * NNB) {
-            int ci = t / NNB, nb = t - ci * NNB;
-            int e[3];
-            ext_decode(sh_ne[ci], g, e);
-            int dx = nb % 3 - 1, dy = (nb / 3) % 3 - 1, dz = (D == 3) ? nb / 9 - 1 : 0;
-            int e2[3] = {e[0] + dx, e[1] + dy, e[2] + dz};
-            int nc = ext_linear(e2, g);
-            if (cell_end[nc] > cell_start[nc]) v = nc;
-        }
-        ccell[t] = v;
-        if (t < MD_NCMAX) ncand[t] = v;
+    // the bounding box dilated by one cell holds every neighbour cell; its cells get a dense local number
+    int lo[3], nb3[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        bool used = (c < D);
+        lo[c] = used ? sh_misc[4 + c] - 1 : 0;
+        nb3[c] = used ? sh_misc[7 + c] - sh_misc[4 + c] + 3 : 1;
     }
+    const int V = nb3[0] * nb3[1] * nb3[2];
+    if (V > MD_BBMAX || V <= 0) bad = true;
+    // 1b. mark the neighbour cells: every (owned cell, offset) resolves its local number once; all lanes of a cell
+    // share the result later (per-lane lookups cost more VALU time than the distance tests)
+    if (!bad)
+        for (int t = tid; t < nne * NNB; t += MD_BT_THREADS) {
+            int ci = t / NNB, nb = t - ci * NNB;
+            int dx = nb % 3 - 1, dy = (nb / 3) % 3 - 1, dz = (D == 3) ? nb / 9 - 1 : 0;
+            int e2[3] = {sh_ne_e[ci][0] + dx, sh_ne_e[ci][1] + dy, sh_ne_e[ci][2] + dz};
+            int nc = ext_linear(e2, g);
+            uint16_t li = 0xffffu;
+            if (cell_end[nc] > cell_start[nc]) {
+                li = (uint16_t)(((e2[2] - lo[2]) * nb3[1] + (e2[1] - lo[1])) * nb3[0] + (e2[0] - lo[0]));
+                lcell[li] = nc; // (the same value from every writer)
+            }
+            ctab[t] = li;
+        }
     __syncthreads();
     MD_STAMP(1);
-    // bitonic sort (ascending; the INF padding ends up last)
-    for (int kk = 2; kk <= M; kk <<= 1)
-        for (int j = kk >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < M; i += MD_BT_THREADS) {
-                int ixj = i ^ j;
-                if (ixj > i) {
-                    bool asc = (i & kk) == 0;
-                    int a = ccell[i], b = ccell[ixj];
-                    if ((a > b) == asc) {
-                        ccell[i] = b;
-                        ccell[ixj] = a;
-                    }
+    MD_STAMP(2);
+    // 1c. unique cells in local order + staging offsets (each cell's staged range is padded to a multiple of 4
+    // entries so that the sweep can read four coordinates with one 16-byte LDS load; pad entries never hit)
+    const int per_c = (MD_BBMAX + MD_BT_THREADS - 1) / MD_BT_THREADS;
+    int my_nu = 0, my_cnt = 0;
+    if (!bad)
+        for (int q = 0; q < per_c; ++q) {
+            int li = tid * per_c + q;
+            if (li < V) {
+                int c = lcell[li];
+                if (c >= 0) {
+                    ++my_nu;
+                    my_cnt += (cell_end[c] - cell_start[c] + 3) & ~3;
                 }
             }
-            __syncthreads();
         }
-    MD_STAMP(2);
-    // unique cells + staging offsets: each thread owns per_c consecutive sorted entries
-    const int per_c = (M + MD_BT_THREADS - 1) / MD_BT_THREADS;
-    // (each cell's staged range is padded to a multiple of 4 entries so that the sweep can read
-    // four coordinates with one 16-byte LDS load; pad entries sit far away and never hit)
-    int my_nu = 0, my_cnt = 0;
-    for (int q = 0; q < per_c; ++q) {
-        int i = tid * per_c + q;
-        if (i < M) {
-            int c = ccell[i];
-            if (c != MD_INF_CELL && (i == 0 || ccell[i - 1] != c)) {
-                ++my_nu;
-                my_cnt += (cell_end[c] - cell_start[c] + 3) & ~3;
-            }
-        }
-    }
     int tot_nu, tot_S;
     int base_nu = block_excl_scan(my_nu, sh_scan, &tot_nu);
     int base_S = block_excl_scan(my_cnt, sh_scan, &tot_S);
-    for (int q = 0; q < per_c; ++q) {
-        int i = tid * per_c + q;
-        if (i < M) {
-            int c = ccell[i];
-            if (c != MD_INF_CELL && (i == 0 || ccell[i - 1] != c)) {
-                ucell[base_nu] = c;
-                coff[base_nu] = base_S;
-                ccnt[base_nu] = cell_end[c] - cell_start[c];
-                ++base_nu;
-                base_S += (cell_end[c] - cell_start[c] + 3) & ~3;
+    if (!bad)
+        for (int q = 0; q < per_c; ++q) {
+            int li = tid * per_c + q;
+            if (li < V) {
+                int c = lcell[li];
+                if (c >= 0) {
+                    ucell[base_nu] = c;
+                    coff[base_nu] = base_S;
+                    ccnt[base_nu] = cell_end[c] - cell_start[c];
+                    lmap[li] = (uint16_t)base_nu;
+                    ++base_nu;
+                    base_S += (cell_end[c] - cell_start[c] + 3) & ~3;
+                }
             }
         }
-    }
     if (tid == 0) coff[tot_nu] = tot_S;
     __syncthreads();
     const int nu = tot_nu;
@@ -275,47 +329,31 @@ __global__ void __launch_bounds__(MD_BT_THREADS)
         atomicMax(&sc->dbg_rmax, nne);
         atomicMax(&sc->dbg_smax, S);
     }
-    if (S >= MD_SCAP) bad = true; // the last slot is the trash slot of the mark sweep
+    if (S >= MD_SCAP || nu > MD_NCMAX) bad = true; // the last slot is the trash slot of the mark sweep
     if (bad) {
         // this tile does not fit the fast path: the host falls back to the two-kernel build
         if (tid == 0) atomicOr(&sc->halo_overflow, 2);
         return;
     }
-    // 1c. resolve every (owned cell, neighbour offset) to its unique-cell index once per tile; all
-    // lanes of a cell share the result (per-lane lookups cost more VALU time than the distance tests)
     for (int t = tid; t < nne * NNB; t += MD_BT_THREADS) {
-        int cell = ncand[t];
-        uint16_t u16 = 0xffffu;
-        if (cell != MD_INF_CELL && nu > 0) {
-            int lo = 0, hi = nu;
-            while (hi - lo > 1) {
-                int mid = (lo + hi) >> 1;
-                if (ucell[mid] <= cell)
-                    lo = mid;
-                else
-                    hi = mid;
-            }
-            if (ucell[lo] == cell) u16 = (uint16_t)lo;
-        }
-        ctab[t] = u16;
+        uint16_t li = ctab[t];
+        ctab[t] = (li == 0xffffu) ? (uint16_t)0xffffu : lmap[li];
     }
+    // staged slot 32 t belongs to unique cell blk2u[t] (replaces a binary search per staged particle)
+    for (int u = tid; u < nu; u += MD_BT_THREADS)
+        for (int t = (coff[u] + 31) >> 5; (t << 5) < coff[u + 1]; ++t) blk2u[t] = (uint16_t)u;
     int myci = 0; // index of my cell in the tile's list of owned cells
     for (int q = 0; q < nne; ++q)
         if (sh_ne[q] == mycell) myci = q;
+    __syncthreads();
     MD_STAMP(3);
     // 2. stage (fp32, relative to the tile origin)
     for (int i = tid; i < S; i += MD_BT_THREADS) {
-        int lo = 0, hi = nu; // last u with coff[u] <= i
-        while (hi - lo > 1) {
-            int mid = (lo + hi) >> 1;
-            if (coff[mid] <= i)
-                lo = mid;
-            else
-                hi = mid;
-        }
-        int off = i - coff[lo];
-        if (off < (int)ccnt[lo]) {
-            double4 p = P[cell_start[ucell[lo]] + off];
+        int u = blk2u[i >> 5];
+        while (coff[u + 1] <= i) ++u;
+        int off = i - coff[u];
+        if (off < (int)ccnt[u]) {
+            double4 p = P[cell_start[ucell[u]] + off];
             px[i] = (float)(p.x - org.x);
             py[i] = (float)(p.y - org.y);
             if constexpr (D == 3) pz[i] = (float)(p.z - org.z);
@@ -325,7 +363,6 @@ __global__ void __launch_bounds__(MD_BT_THREADS)
             if constexpr (D == 3) pz[i] = 1.0e30f;
         }
     }
-    __syncthreads();
     // this particle's own index in the staged image (its cell is its own neighbour, so it is staged)
     int self_q = -1;
     if (active) {
@@ -336,7 +373,6 @@ __global__ void __launch_bounds__(MD_BT_THREADS)
     MD_STAMP(4);
     // 3. sweep: mark + per-cell hit masks
     const int wt = tile * (MD_TILE / 64) + (pt >> 6);
-    uint16_t *rowbase = nlist16 + ((size_t)wt * maxn) * 64;
     const int n0 = half ? nA : 0, n1 = half ? NNB : nA;
     unsigned long long hmask[MD_HALF_CELLS];
     int qstart[MD_HALF_CELLS];
@@ -353,7 +389,10 @@ __global__ void __launch_bounds__(MD_BT_THREADS)
         }
     }
     if (too_big) atomicOr(&sc->halo_overflow, 4);
-    if (half == 0) cntA[pt] = cnt;
+    if (half == 0)
+        cntA[pt] = cnt;
+    else
+        cntB[pt] = cnt;
     __syncthreads();
     MD_STAMP(5);
     // 4. compact the referenced particles into the halo
@@ -386,20 +425,10 @@ __global__ void __launch_bounds__(MD_BT_THREADS)
             if (H > hcap || (H + 1) * rs > 65535) atomicOr(&sc->halo_overflow, 1);
         }
     }
-    __syncthreads();
-    MD_STAMP(6);
-    // 5. emit: write the rows from the hit masks.  The second-half thread appends after the first
-    // half's entries.
-    const int cA = cntA[pt];
-    const int start = half ? cA : 0;
-    int endc = start;
-    if (active) endc = tile_sweep_emit(hmask, qstart, newidx, rowbase, lane, maxn, start, rs);
-    __syncthreads();
-    MD_STAMP(7);
-    if (half == 1) cntA[pt] = endc; // total = cA + cB
-    __syncthreads();
+    // row lengths, padded wave maxima
+    const int totp = cntA[pt] + cntB[pt]; // (cntA/cntB were published before the barrier inside block_excl_scan)
     if (half == 0) {
-        int tot = active ? cntA[pt] : 0;
+        int tot = active ? totp : 0;
         if (active) {
             nneigh[k] = tot;
             if (tot > maxn) {
@@ -409,10 +438,59 @@ __global__ void __launch_bounds__(MD_BT_THREADS)
         }
         int m = wave_max_i(tot);
         m = (m + 3) & ~3;
-        if (m > maxn) m = maxn;
-        for (int t = tot; t < m; ++t) rowbase[row_off(t, lane)] = (uint16_t)(H * rs);
-        if (lane == 0) nmax_tile[wt] = m;
+        if (m > maxn) m = maxn; // maxn is a multiple of 4
+        if (lane == 0) {
+            nmax_tile[wt] = m;
+            sh_misc[10 + (pt >> 6)] = m;
+        }
     }
+    MD_STAMP(6);
+    // 5. emit: every thread walks its hit masks into its particle's LDS row (the second-half thread appends after
+    // the first half's entries), then the block writes the rows out in the transposed groups-of-four layout with
+    // coalesced 8-byte stores, translating staged indices to halo offsets on the way.
+    uint16_t *rowbuf = (uint16_t *)pool;
+    const unsigned sent = (unsigned)(H * rs) & 0xffffu;
+    __syncthreads(); // (phase-1 arrays are dead from here on)
+    uint16_t *grow = nlist16 + ((size_t)wt * maxn) * 64;
+    if (active) {
+        const int start = half ? cntA[pt] : 0;
+        tile_sweep_emit_lds(hmask, qstart, newidx, rowbuf + (size_t)pt * MD_ROWPITCH, grow, lane, maxn, start, rs);
+    }
+    __syncthreads();
+    {
+        // thread -> (wave wl, lane, first group): 8 waves cover 4 row-waves x 2 group parities
+        const int wl = (tid >> 6) & 3, ln = tid & 63, gpar = tid >> 8;
+        const int mw = sh_misc[10 + wl];
+        const int pglob = wl * 64 + ln; // particle of the tile
+        int totw = cntA[pglob] + cntB[pglob];
+        if (tile * MD_TILE + pglob >= n) totw = 0;
+        if (totw > maxn) totw = maxn;
+        unsigned long long *out = (unsigned long long *)(nlist16 + ((size_t)(tile * (MD_TILE / 64) + wl) * maxn) * 64);
+        const uint16_t *rrow = rowbuf + (size_t)pglob * MD_ROWPITCH;
+        const unsigned long long sent4 = (unsigned long long)sent * 0x0001000100010001ull;
+        for (int gq = gpar; gq < (mw >> 2); gq += 2) {
+            int valid = totw - 4 * gq; // entries of this word that exist
+            if (4 * gq < MD_ROWPITCH) {
+                unsigned long long w = *(const unsigned long long *)(rrow + 4 * gq); // four staged indices
+                unsigned long long o = 0ull;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    unsigned q = (unsigned)(w >> (16 * j)) & 0xffffu;
+                    unsigned v = (j < valid) ? (unsigned)newidx[q < MD_SCAP ? q : 0] * (unsigned)rs : sent;
+                    o |= (unsigned long long)(v & 0xffffu) << (16 * j);
+                }
+                out[(size_t)gq * 64 + ln] = o;
+            } else {
+                // beyond the row buffer: real entries were written by the walk itself, only the padding is missing
+                uint16_t *g16 = (uint16_t *)(out + (size_t)gq * 64 + ln);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (j >= valid) g16[j] = (uint16_t)sent;
+            }
+        }
+        (void)sent4;
+    }
+    MD_STAMP(7);
     MD_STAMP(8);
 #undef MD_STAMP
 }
