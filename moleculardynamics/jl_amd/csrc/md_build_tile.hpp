@@ -25,31 +25,6 @@
 #define MD_INF_CELL 0x7fffffff
 #define MD_SWB 8
 
-// exclusive scan of one int per thread over the block; returns the prefix, *total gets the
-// block sum.  lds: >= 16 ints.  Contains barriers: call from uniform control flow.
-__device__ __forceinline__ int block_excl_scan(int v, int *lds, int *total)
-{
-    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    int inc = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        int t = __shfl_up(inc, off);
-        if (lane >= off) inc += t;
-    }
-    __syncthreads();
-    if (lane == 63) lds[w] = inc;
-    __syncthreads();
-    int base = 0, tot = 0;
-    int nw = (blockDim.x + 63) >> 6;
-    for (int i = 0; i < nw; ++i) {
-        int t = lds[i];
-        if (i < w) base += t;
-        tot += t;
-    }
-    *total = tot;
-    return base + inc - v;
-}
-
 // Sweep of a thread's share of the 27 (9) neighbour cells over the LDS image.  The cell loop is
 // fully unrolled (MD_HALF_CELLS iterations, cells beyond the thread's share are skipped) so
 // that the per-cell hit masks live in registers:

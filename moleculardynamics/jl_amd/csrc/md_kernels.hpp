@@ -183,6 +183,31 @@ __device__ __forceinline__ double block_sum(double v, double *lds /* >= 16 doubl
     return r;
 }
 
+// exclusive scan of one int per thread over the block; returns the prefix, *total gets the
+// block sum.  lds: >= 16 ints.  Contains barriers: call from uniform control flow.
+__device__ __forceinline__ int block_excl_scan(int v, int *lds, int *total)
+{
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        int t = __shfl_up(inc, off);
+        if (lane >= off) inc += t;
+    }
+    __syncthreads();
+    if (lane == 63) lds[w] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+    int nw = (blockDim.x + 63) >> 6;
+    for (int i = 0; i < nw; ++i) {
+        int t = lds[i];
+        if (i < w) base += t;
+        tot += t;
+    }
+    *total = tot;
+    return base + inc - v;
+}
+
 // XCD-aware bijective remap: hardware deals consecutive block ids round-robin over the 8
 // XCDs; give each XCD one contiguous range of logical tiles so a tile's neighbours (whose
 // positions it gathers) sit in the same XCD's L2.  Speed only, never correctness.
@@ -841,7 +866,7 @@ __device__ __forceinline__ void tile_pair_loop(const unsigned char *smem, const 
                                                ushort4 (&jn)[MD_UNROLL / 4], int m, int H,
                                                const double4 &pi, const PotParams &pp, unsigned long long *rin64,
                                                double rin2, unsigned long long &acc, int &cin, double &fx, double &fy,
-                                               double &fz, double &us, double &ws)
+                                               double &fz, double &us, double &ws, const uint16_t *remap8 = nullptr)
 {
     constexpr int RS = UNIFORM ? 24 : 32;
     constexpr int G = MD_UNROLL / 4; // index groups per iteration; jn holds the first G groups, loaded by the caller
@@ -896,7 +921,7 @@ __device__ __forceinline__ void tile_pair_loop(const unsigned char *smem, const 
                 d2 = __builtin_fma(dzq[q], dzq[q], d2);
                 if constexpr (PRUNE) {
                     if (d2 <= rin2) { // (padding entries are 1e100 away: they never survive)
-                        acc |= (unsigned long long)o[q] << (16 * (cin & 3));
+                        acc |= (unsigned long long)(remap8 ? (unsigned)remap8[o[q] >> 3] : o[q]) << (16 * (cin & 3)); // (inner halo: its own offsets)
                         ++cin;
                         if ((cin & 3) == 0) {
                             rin64[(size_t)((cin >> 2) - 1) * 64] = acc;
@@ -948,7 +973,7 @@ __device__ __forceinline__ void tile_pair_loop(const unsigned char *smem, const 
             if constexpr (PRUNE) {
                 if (d2 <= rin2) { // (padding entries are 1e100 away: they never survive)
                     // four 16-bit entries of a row are one 8-byte word (row_off): write it when it is full
-                    acc |= (unsigned long long)o[q] << (16 * (cin & 3));
+                    acc |= (unsigned long long)(remap8 ? (unsigned)remap8[o[q] >> 3] : o[q]) << (16 * (cin & 3)); // (inner halo: its own offsets)
                     ++cin;
                     if ((cin & 3) == 0) {
                         rin64[(size_t)((cin >> 2) - 1) * 64] = acc;
@@ -974,7 +999,7 @@ __device__ __forceinline__ void tile_pair_loop(const unsigned char *smem, const 
 // PRUNE epilogue: pad the inner row to the wave's longest, record the prune positions x1 and the largest
 // displacement since the build.
 template <int D, bool UNIFORM>
-__device__ __forceinline__ void tile_prune_tail(DevState &s, Scalars *sc, int H, int k, bool active, int lane, int wt,
+__device__ __forceinline__ void tile_prune_tail(DevState &s, Scalars *sc, int H /* sentinel slot of the image the inner rows index */, int k, bool active, int lane, int wt,
                                                 const double4 &pi, unsigned long long *rin64, int32_t *nmax_in,
                                                 unsigned long long acc, int cin)
 {
@@ -1182,7 +1207,8 @@ __global__ void __launch_bounds__(MD_TILE)
                 const int32_t *__restrict__ halo_count, double dt, double skin_half, double inner_half, int use_d1,
                 double *__restrict__ partials, int nblk_total, Scalars *__restrict__ sc, int step,
                 uint16_t *__restrict__ rows_in, int32_t *__restrict__ nmax_in, double rin2,
-                long long *__restrict__ stamps)
+                long long *__restrict__ stamps, uint32_t *__restrict__ halo_in, int hcap_in,
+                int32_t *__restrict__ halo_in_count)
 {
 #define MD_SSTAMP(i)                                                                                   \
     do {                                                                                               \
@@ -1302,10 +1328,101 @@ __global__ void __launch_bounds__(MD_TILE)
     MD_SSTAMP(2);
     __syncthreads();
     MD_SSTAMP(3);
+    // Prune step with an inner halo: the ordinary steps that follow stage only the halo particles within
+    // (cutoff + inner skin) of the box around the tile's own particles -- every entry an inner row can hold points
+    // there -- about 2/3 of the outer halo: a third less staging traffic and a smaller LDS image (more resident
+    // blocks).  Here: box of the own positions, one clamped-distance test per staged record, an ordered block scan
+    // that numbers the kept records, the inner halo list, and a table old offset -> new offset that the row
+    // append below applies.
+    const uint16_t *remap8 = nullptr;
+    int Hsent = H;
+    if constexpr (PRUNE) {
+        if (halo_in) {
+            __shared__ double sh_bb[MD_TILE / 64][6];
+            __shared__ int sh_scan2[16];
+            __shared__ int sh_hin;
+            uint16_t *rm = (uint16_t *)(smem + ((((size_t)(H + 1) * RS) + 15) & ~(size_t)15));
+            const double big = 1.0e300;
+            double lo3[3], hi3[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                double v = (c < D) ? xn[c] : 0.0;
+                lo3[c] = -wave_max_d((active && c < D) ? -v : -big);
+                hi3[c] = wave_max_d((active && c < D) ? v : -big);
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    sh_bb[threadIdx.x >> 6][c] = lo3[c];
+                    sh_bb[threadIdx.x >> 6][3 + c] = hi3[c];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                lo3[c] = big;
+                hi3[c] = -big;
+                for (int w = 0; w < MD_TILE / 64; ++w) {
+                    lo3[c] = fmin(lo3[c], sh_bb[w][c]);
+                    hi3[c] = fmax(hi3[c], sh_bb[w][3 + c]);
+                }
+            }
+            int carry = 0;
+            for (int h0 = 0; h0 < H; h0 += 8 * MD_TILE) {
+                // thread t owns 8 CONSECUTIVE slots: the scan keeps the halo order
+                const int hb = h0 + 8 * (int)threadIdx.x;
+                unsigned near = 0u;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    int h = hb + i;
+                    if (h < H) {
+                        const double *rec = (const double *)(smem + (size_t)h * RS);
+                        double dd = 0.0;
+#pragma unroll
+                        for (int c = 0; c < D; ++c) {
+                            double xc = rec[c];
+                            double dl = fmax(fmax(lo3[c] - xc, xc - hi3[c]), 0.0);
+                            dd = __builtin_fma(dl, dl, dd);
+                        }
+                        if (dd <= rin2) near |= 1u << i;
+                    }
+                }
+                int tot;
+                int base = carry + block_excl_scan(__popc(near), sh_scan2, &tot);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    int h = hb + i;
+                    if (h < H) {
+                        bool nr = (near >> i) & 1u;
+                        // (a record that is not kept can not be referenced by a kept entry; point it at the sentinel)
+                        rm[((unsigned)h * RS) >> 3] = nr ? (uint16_t)((unsigned)base * RS) : (uint16_t)0xffffu;
+                        if (nr) {
+                            if (base < hcap_in) halo_in[(size_t)bid * hcap_in + base] = hl[h];
+                            ++base;
+                        }
+                    }
+                }
+                carry += tot;
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) {
+                sh_hin = carry;
+                halo_in_count[bid] = carry;
+                if (carry > hcap_in || (size_t)(carry + 1) * RS > 65535) {
+                    // does not fit the ordinary steps' LDS image: the host turns the inner halo off and redoes the step
+                    atomicOr(&sc->halo_overflow, 16);
+                    atomicMin(&sc->first_viol, step);
+                }
+            }
+            __syncthreads();
+            Hsent = sh_hin;
+            remap8 = rm;
+        }
+    }
     double fx = 0.0, fy = 0.0, fz = 0.0, us = 0.0, ws = 0.0;
-    tile_pair_loop<D, POT, UNIFORM, WANT_UW, PRUNE>(smem, row4, jn, m, H, pi, pp, rin64, rin2, acc, cin, fx, fy, fz, us, ws);
+    tile_pair_loop<D, POT, UNIFORM, WANT_UW, PRUNE>(smem, row4, jn, m, H, pi, pp, rin64, rin2, acc, cin, fx, fy, fz, us, ws, remap8);
     MD_SSTAMP(4);
-    if constexpr (PRUNE) tile_prune_tail<D, UNIFORM>(s, sc, H, k, active, lane, wt, pi, rin64, nmax_in, acc, cin);
+    if constexpr (PRUNE) tile_prune_tail<D, UNIFORM>(s, sc, Hsent, k, active, lane, wt, pi, rin64, nmax_in, acc, cin);
     double ke = 0.0;
     if (active) {
         const double fn[3] = {fx, fy, fz};

@@ -185,6 +185,14 @@ struct md_ctx {
     // fused step loop (k_step_tile): ping-pong state records; `fz_a` = the buffer set that holds the latest complete
     // step: records rec[fz_a], forces sb[cur ^ fz_a].f, positions sb[cur ^ fz_a].pos  (set 0 is the canonical state)
     DBuf<double2> rec[2];
+    // inner halo of the fused loop: per tile, the outer-halo records within (cutoff + inner skin) of the tile's own
+    // particles at the last prune step; ordinary steps stage only those
+    DBuf<uint32_t> halo_in;
+    DBuf<int32_t> halo_in_count;
+    int hcap_in = 0;
+    size_t tile_lds_in = 0;
+    bool allow_inner_halo = true;
+    bool inner_halo_live = false; // the current inner rows index the inner halo image (written by a fused prune step)
     int fz_a = 0;
     bool allow_fused = true;
     double d1_rate = 0.0;       // growth per step of the largest displacement since a reference (measured)
@@ -622,6 +630,14 @@ void rebuild_t(md_ctx *c)
         for (int d = 0; d < c->dim; ++d) c->x1[d].ensure(c->ncap);
         c->nlist16_in.ensure((size_t)c->ntiles * c->maxn * 64);
         c->nmax_tile_in.ensure(c->ntiles);
+        // inner halo: capacity = what fits the LDS budget that lets one more block reside per CU than the outer image
+        // (uniform: 4 x 40 KB; per-particle diameters: 3 x 53 KB), never more than the outer halo itself
+        const size_t target = (c->tile_rs == 24) ? (40 * 1024 - 256) : (53 * 1024);
+        int cap_in = (int)std::min<size_t>((size_t)c->hstride, target / c->tile_rs - 1);
+        c->hcap_in = std::max(cap_in, 1);
+        c->tile_lds_in = (((size_t)(c->hcap_in + 1) * c->tile_rs) + 15) & ~(size_t)15;
+        c->halo_in.ensure((size_t)c->nblk * c->hcap_in);
+        c->halo_in_count.ensure(c->nblk);
     }
 }
 
@@ -684,7 +700,9 @@ void launch_force_tpu(md_ctx *c, bool want_uw, bool kick, double dt, int step, i
     int n = (int)c->n;
     int nb = c->nblk;
     bool prune_step = rows == 0 && c->prune_on && !c->inner_valid && kick;
-    bool use_inner = rows == 0 && c->inner_valid;
+    // (inner rows written by a fused prune step index the INNER halo image, which this kernel does not stage: the
+    // outer rows serve instead -- a superset, valid as long as the list is)
+    bool use_inner = rows == 0 && c->inner_valid && !c->inner_halo_live;
     const uint16_t *rows16 = use_inner ? c->nlist16_in.p : c->nlist16.p;
     const int32_t *rowmax = use_inner ? c->nmax_tile_in.p : c->nmax_tile.p;
     DevState s = c->dev(c->cur);
@@ -703,7 +721,7 @@ void launch_force_tpu(md_ctx *c, bool want_uw, bool kick, double dt, int step, i
         auto kfn = k_force_tile<D, POT, UNIFORM, UW, KK, PR>;                                                       \
         if (c->tile_lds > attr_bytes) {                                                                             \
             HIPCHK(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,               \
-                                       (int)(160 * 1024 - 256)));                                                   \
+                                       (int)(160 * 1024 - 2048)));                                                  \
             attr_bytes = 160 * 1024;                                                                                \
         }                                                                                                           \
         kfn<<<nb, MD_TILE, c->tile_lds, c->stream>>>(n, s, c->pp, rows16, c->maxn, rowmax, c->halo.p, c->hcap,      \
@@ -961,6 +979,26 @@ void launch_step_tpu(md_ctx *c, bool want_uw, double dt, int step)
         for (int d = 0; d < 3; ++d) s.x1[d] = c->x1[d].p; // the prune step writes the new reference positions
         k_reset_d1<<<1, 1, 0, c->stream>>>(c->scal.p, step - 1);
     }
+    // which halo image the launch stages: the outer one (prune steps, and whenever there is no inner halo), or the
+    // inner one the last prune step left behind
+    const bool ih = c->allow_inner_halo && c->prune_on && c->hcap_in > 0;
+    const uint32_t *halo_p = c->halo.p;
+    int halo_cap = c->hcap;
+    const int32_t *halo_cnt = c->halo_count.p;
+    size_t lds_bytes = c->tile_lds;
+    uint32_t *hin_p = nullptr;
+    if (prune_step && ih) {
+        hin_p = c->halo_in.p;
+        lds_bytes = ((c->tile_lds + 15) & ~(size_t)15) + (c->tile_lds / 8 + 8) * 2; // + the offset translation table
+        c->inner_halo_live = true;
+    } else if (prune_step) {
+        c->inner_halo_live = false;
+    } else if (use_inner && c->inner_halo_live) {
+        halo_p = c->halo_in.p;
+        halo_cap = c->hcap_in;
+        halo_cnt = c->halo_in_count.p;
+        lds_bytes = c->tile_lds_in;
+    }
     const int a = c->fz_a;
     StateBufs &A = c->sb[c->cur ^ a], &B = c->sb[c->cur ^ a ^ 1];
     StepBufs sbufs{};
@@ -978,13 +1016,14 @@ void launch_step_tpu(md_ctx *c, bool want_uw, double dt, int step)
         static int attr_dev_mask = 0;                                                                               \
         if (!(attr_dev_mask & (1 << (c->device & 31)))) {                                                           \
             HIPCHK(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,               \
-                                       (int)(160 * 1024 - 256)));                                                   \
+                                       (int)(160 * 1024 - 2048)));                                                  \
             attr_dev_mask |= 1 << (c->device & 31);                                                                 \
         }                                                                                                           \
-        kfn<<<nb, MD_TILE, c->tile_lds, c->stream>>>(n, s, sbufs, c->pp, rows16, c->maxn, rowmax, c->halo.p, c->hcap, \
-                                                     c->halo_count.p, dt, skin_half, inner_half, use_d1,            \
-                                                     c->partials.p, nb, c->scal.p, step, c->nlist16_in.p,           \
-                                                     c->nmax_tile_in.p, rin * rin, c->dbg_stamps.p);                \
+        kfn<<<nb, MD_TILE, lds_bytes, c->stream>>>(n, s, sbufs, c->pp, rows16, c->maxn, rowmax, halo_p, halo_cap,   \
+                                                   halo_cnt, dt, skin_half, inner_half, use_d1,                     \
+                                                   c->partials.p, nb, c->scal.p, step, c->nlist16_in.p,             \
+                                                   c->nmax_tile_in.p, rin * rin, c->dbg_stamps.p, hin_p,            \
+                                                   c->hcap_in, c->halo_in_count.p);                                 \
     } while (0)
     prof_begin(c);
     if (prune_step && c->prof_open) c->prof_prune_acc++;
@@ -1132,6 +1171,7 @@ static int create_common(int dim, int64_t n_global, int64_t n_cap, bool domain, 
         if (const char *e = getenv("MDHIP_NO_FUSED_BUILD")) ctx->allow_fused_build = !(e[0] == '1');
         if (const char *e = getenv("MDHIP_INNER_SKIN")) ctx->inner_skin_req = atof(e);
         if (const char *e = getenv("MDHIP_NO_FUSED_STEP")) ctx->allow_fused = !(e[0] == '1');
+        if (const char *e = getenv("MDHIP_NO_INNER_HALO")) ctx->allow_inner_halo = !(e[0] == '1');
         // default potential: LennardJones() -- src/potentials.jl:52-64
         ctx->pot_kind = POT_LJ;
         ctx->pp.p[0] = 1.0;
@@ -1592,13 +1632,20 @@ int md_run(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, double tau, dou
                         s, win_end, h.first_viol < win_end ? h.first_viol : -1, d1, ctx->d1_rate, ctx->safety,
                         (long long)ctx->steps_since_build, (long long)R, (long long)(L == INT64_MAX ? -1 : L),
                         prune_steps.size());
+            if (h.halo_overflow & 16) {
+                // a tile's inner halo did not fit the LDS image planned for the ordinary steps: the prune step
+                // recorded itself as violated; go on without inner halos (the list build below resets the flag)
+                ctx->allow_inner_halo = false;
+            }
             if (h.first_viol < win_end) {
                 // everything from step m's force evaluation on was skipped on the device: refresh the
                 // rows at the drifted positions and resume with the force half of step m
                 int m = h.first_viol;
-                if (m < s) throw HipError("internal: stale displacement-violation index");
+                // (fused loop: the step launched again after the previous violation can flag ITSELF -- its prune
+                // found a tile whose inner halo does not fit -- which is seen only now: m == s - 1, nothing after it ran)
+                if (m < s - 1 || (m < s && !fused)) throw HipError("internal: stale displacement-violation index");
                 ctx->st_viol++;
-                bool m_was_prune = false;
+                bool m_was_prune = (h.halo_overflow & 16) != 0;
                 for (int p : prune_steps)
                     if (p == m) m_was_prune = true;
                 ctx->steps_since_build += (m - s) + 1;
