@@ -1254,16 +1254,18 @@ __global__ void __launch_bounds__(MD_TILE)
     for (int g = 0; g < G; ++g) jn[g] = row4[(size_t)((4 * g < m) ? g : 0) * 64];
     MD_SSTAMP(1);
     // stage the halo: index loads, then the record gathers, then drift + periodic shift + LDS writes
-    for (int h0 = 0; h0 <= H; h0 += 8 * MD_TILE) {
-        uint32_t idx[8];
+    // (ordinary steps stage the inner halo, ~1350 records: batches of 6 keep the kernel within 128 registers)
+    constexpr int NB = (!PRUNE && UNIFORM && !WANT_UW) ? 6 : 8;
+    for (int h0 = 0; h0 <= H; h0 += NB * MD_TILE) {
+        uint32_t idx[NB];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < NB; ++i) {
             int h = h0 + i * MD_TILE + threadIdx.x;
             idx[i] = (h < H) ? hl[h] : 0xffffffffu;
         }
-        double2 r0[8], r1[8], r2[8], r3[8];
+        double2 r0[NB], r1[NB], r2[NB], r3[NB];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < NB; ++i) {
             bool ok = idx[i] != 0xffffffffu;
             size_t j = ok ? (size_t)(idx[i] & 0x3ffffffu) : 0;
             r0[i] = RA0[j];
@@ -1272,7 +1274,7 @@ __global__ void __launch_bounds__(MD_TILE)
             if constexpr (!UNIFORM) r3[i] = RA3[j];
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < NB; ++i) {
             int h = h0 + i * MD_TILE + threadIdx.x;
             bool ok = idx[i] != 0xffffffffu;
             double x = __builtin_fma(adt, r1[i].y, r0[i].x);

@@ -199,3 +199,86 @@ def test_zstd_roundtrip_and_async_writer(tmp_path):
     w.submit(lambda: 1 / 0)
     with pytest.raises(ZeroDivisionError):
         w.close()
+
+
+# ---------------------------------------------------------------- julia/MDHip.jl against include/mdhip.h
+_C2JL = {"int": "Cint", "int64_t": "Int64", "uint64_t": "UInt64", "double": "Float64", "double*": "Ptr{Float64}",
+         "int32_t*": "Ptr{Int32}", "md_ctx*": "Ptr{Cvoid}", "md_ctx**": "Ptr{Ptr{Cvoid}}", "char*": "Cstring",
+         "int*": "Ptr{Cint}", "int64_t*": "Ptr{Int64}", "void*": "Ptr{Cvoid}", "md_stats*": "Ptr{MdStats}"}
+
+
+def _header_prototypes():
+    text = open(os.path.join(ROOT, "include", "mdhip.h")).read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(const\s+char\s*\*|int)\s*(md_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", text, flags=re.S):
+        ret = "Cstring" if "char" in m.group(1) else "Cint"
+        args = []
+        for a in [x.strip() for x in m.group(3).split(",") if x.strip() and x.strip() != "void"]:
+            a = re.sub(r"\bconst\b", "", a)
+            a = re.sub(r"\[\s*\d*\s*\]", "*", a)              # array parameter = pointer
+            stars = a.count("*")
+            base = re.sub(r"[*]", " ", a).split()
+            ctype = base[0] if base[0] != "unsigned" else " ".join(base[:2])
+            args.append(_C2JL[ctype + "*" * stars])
+        protos[m.group(2)] = (ret, args)
+    return protos
+
+
+def _split_top(s):
+    out, depth, cur = [], 0, ""
+    for ch in s:
+        if ch in "({[":
+            depth += 1
+        if ch in ")}]":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur.strip())
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur.strip())
+    return out
+
+
+def _julia_calls():
+    src = open(os.path.join(ROOT, "julia", "MDHip.jl")).read()
+    calls = []
+    for m in re.finditer(r"ccall\(\(:(md_[a-z0-9_]+),\s*LIB\),\s*(\w+),\s*\(", src):
+        i, depth = m.end(), 1
+        while depth:                               # the argument-type tuple
+            depth += {"(": 1, ")": -1}.get(src[i], 0)
+            i += 1
+        calls.append((m.group(1), m.group(2), _split_top(src[m.end():i - 1])))
+    for m in re.finditer(r"@ccall\s+gc_safe=true\s+LIB\.(md_[a-z0-9_]+)\(", src):
+        i, depth = m.end(), 1
+        while depth:
+            depth += {"(": 1, ")": -1}.get(src[i], 0)
+            i += 1
+        ret = re.match(r"::(\w+)", src[i:]).group(1)
+        types = [re.search(r"::([\w{}]+)\s*$", a).group(1) for a in _split_top(src[m.end():i - 1])]
+        calls.append((m.group(1), ret, types))
+    return calls
+
+
+def test_julia_binding_matches_the_header():
+    """No Julia in the build image: every ccall / @ccall of julia/MDHip.jl is checked statically against the C
+    prototypes of include/mdhip.h -- symbol exists, return type, argument count, argument types."""
+    protos = _header_prototypes()
+    assert set(protos) == set(_lib.EXPORTS)            # the little parser sees the whole header
+    calls = _julia_calls()
+    assert len(calls) >= 10
+    for name, ret, types in calls:
+        assert name in protos, f"MDHip.jl calls {name}, which include/mdhip.h does not declare"
+        pret, pargs = protos[name]
+        assert ret == pret, f"{name}: return type {ret} vs {pret}"
+        assert types == pargs, f"{name}: argument types {types} vs header {pargs}"
+    used = {c[0] for c in calls}
+    for needed in ("md_create", "md_destroy", "md_set_potential", "md_set_potential_source", "md_upload", "md_download",
+                   "md_run", "md_run_brownian", "md_fire_minimize", "md_last_error"):
+        assert needed in used, f"MDHip.jl does not bind {needed}"
+    src = open(os.path.join(ROOT, "julia", "MDHip.jl")).read()
+    for name in ("run_simulation!", "minimize!", "fire_minimize!", "write_to_file_lammps", "traj_name", "log_times",
+                 "compress", "Brownian", "evaluate(p::PseudoHS", "evaluate(p::Polydisperse"):
+        assert name in src
