@@ -2689,6 +2689,19 @@ int md_dom_run_window(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, doub
     dom_require(ctx);
     auto &d = ctx->dom;
     if (!d.comm) throw HipError("md_dom_run_window: no communicator (md_dom_comm_init first)");
+    // A failure on this rank between the per-step collectives would leave its peers blocked inside theirs: abort the
+    // communicator first so that they fail fast instead of hanging (the handle needs md_dom_comm_init again).
+    struct AbortGuard {
+        md_ctx *c;
+        bool armed = true;
+        ~AbortGuard()
+        {
+            if (armed && c->dom.comm && g_rccl.CommAbort) {
+                (void)g_rccl.CommAbort(c->dom.comm);
+                c->dom.comm = nullptr;
+            }
+        }
+    } guard{ctx};
     int rc = md_dom_async_begin(ctx, nsteps, dt, ensemble, tau, nf, ktemp, r1, r2, prune_interval, d.own_flag.p,
                                 d.own_kuw.p);
     if (rc != 0) return rc;
@@ -2726,6 +2739,7 @@ int md_dom_run_window(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, doub
             }
         }
     }
+    guard.armed = false;
     return md_dom_async_end(ctx, apply_pending_scale, first_viol, uwk, info);
     API_END
 }

@@ -460,9 +460,12 @@ class DomainDevice:
             return
         ex = self.ex
         torch = ex.torch
-        if not ex.p2p_on_device:
+        # MDHIP_RCCL_PATH: the shared object the library binds its collectives from.  Default: the RCCL PyTorch itself
+        # has loaded.  (tests/shim/libncclshim.so stands in for it when several ranks share the one GPU of a test box.)
+        override = os.environ.get("MDHIP_RCCL_PATH", "")
+        if not ex.p2p_on_device and not override:
             raise MdhipError("the native step loop needs one GPU per rank (RCCL); use run_async/run under gloo")
-        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        path = override or os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
         path_b = path.encode() if os.path.exists(path) else None
         ident = torch.zeros(128, dtype=torch.uint8)
         if self.rank == 0:

@@ -26,6 +26,7 @@ def main():
     kT = float(os.environ.get("DOM_KT", "2.0"))
     nsteps = int(os.environ.get("DOM_STEPS", "60"))
     nvt = os.environ.get("DOM_NVT", "0") == "1"
+    dt = float(os.environ.get("DOM_DT", "0.002"))
     s = lj_system(n, kT=kT, permute=777)     # shuffled ids: ownership is by position, not by index
     if os.environ.get("DOM_ELONG", "0") == "1":
         # the weak-scaling bench's geometry: the global box is `world` cubes long in x
@@ -60,7 +61,7 @@ def main():
         d.upload_global(s["x"], s["v"], s["f"], s["img"], s["diam"])
         d.builds = 0
         runner = {"0": d.run, "1": d.run_async, "native": d.run_native}[os.environ.get("DOM_ASYNC", "0")]
-        Ue, We, Ke = runner(nsteps, 0.002, ens, 0.1, nf, kt, r1, r2)
+        Ue, We, Ke = runner(nsteps, dt, ens, 0.1, nf, kt, r1, r2)
         X, V, F, IM = d.gather_global()
         stats = (d.builds, d.violations, d.counts(), d.stats()["prunes"])
     ok = True
@@ -75,7 +76,7 @@ def main():
         with MDDevice(3, n, s["box"], 2.5, device_id=0) as g:
             g.set_potential(0, LJ)
             g.upload(s["x"], s["v"], s["f"], s["img"], s["diam"])
-            U1, W1, K1 = g.run(nsteps, 0.002, ens, 0.1, nf, kt, r1, r2)
+            U1, W1, K1 = g.run(nsteps, dt, ens, 0.1, nf, kt, r1, r2)
             x1, v1, f1, im1 = g.download()
         dx, dv = np.abs(X - x1).max(), np.abs(V - v1).max()
         print(f"[dom] {nsteps} steps {'NVT' if nvt else 'NVE'}: dx={dx:.2e} dv={dv:.2e} dK={abs(Ke-K1)/K1:.2e} "

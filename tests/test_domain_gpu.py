@@ -11,6 +11,18 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+SHIM = os.path.join(ROOT, "tests", "shim", "libncclshim.so")
+
+
+def _build_shim():
+    """tests/shim/nccl_shim.cpp: the stand-in for librccl.so that lets the library's native window loop run with
+    several ranks on ONE GPU (collectives through shared memory)."""
+    src = os.path.join(ROOT, "tests", "shim", "nccl_shim.cpp")
+    if not os.path.exists(SHIM) or os.path.getmtime(SHIM) < os.path.getmtime(src):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-fPIC", "-shared", "--offload-arch=gfx950", "-o", SHIM, src, "-lrt"])
+    return SHIM
+
+
 def _launch(nproc, env_extra, port):
     env = dict(os.environ)
     env.update(env_extra)
@@ -40,6 +52,13 @@ def _launch(nproc, env_extra, port):
     (2, 1, "device", "async-prune-poly"), (3, 0, "", "sync-poly"),
     # the weak-scaling bench's geometry: one cube per rank, the global box `world` cubes long in x
     (2, 1, "device", "async-prune-elong"), (3, 1, "device", "async-elong"),
+    # the NATIVE window loop (md_dom_run_window: collectives issued by the library) with 2 and 3 real ranks: the
+    # RCCL entry points are bound from tests/shim/libncclshim.so, which moves the data through shared memory
+    (2, 0, "device", "shim-native"), (2, 1, "device", "shim-native"), (3, 1, "device", "shim-native"),
+    (2, 1, "device", "shim-native-prune"), (3, 0, "device", "shim-native-prune"),
+    # BASELINE configs[3]'s geometry (a cube cut into slabs, as bench.py --config 4 does) at 27000 particles: slabs
+    # of 10.4 (3 ranks: 3 cells wide) -- and the native loop on it
+    (3, 0, "device", "async-prune-cfg4"), (2, 0, "device", "shim-native-prune-cfg4"),
 ])
 def test_slab_decomposition_matches_single_gpu(nproc, nvt, stage, mode):
     # N=8000 -> L=20.7: 2 slabs of 10.4, 3 slabs of 6.9 (>= 2 cells each); kT=2 and dt=0.002 make
@@ -47,11 +66,25 @@ def test_slab_decomposition_matches_single_gpu(nproc, nvt, stage, mode):
     # stage == "device": exchange buffers live on the GPU (the RCCL-path plumbing) although gloo carries them
     env = {"DOM_KT": "2.0", "DOM_STEPS": "60", "DOM_NVT": str(nvt), "MDHIP_DOM_STAGE": stage,
            "DOM_ASYNC": "native" if "native" in mode else ("1" if "async" in mode else "0"),
+           "MDHIP_RCCL_PATH": _build_shim() if mode.startswith("shim") else "",
            "DOM_PRUNE": "1" if "prune" in mode else "0", "DOM_STEPS": "120" if "prune" in mode else "60",
            "DOM_POLY": "1" if mode.endswith("poly") else "0", "DOM_ELONG": "1" if mode.endswith("elong") else "0",
-           "DOM_N": "8232" if mode.endswith("elong") else "8000",      # 8232 = 2 * 4116 = 3 * 2744
+           "DOM_N": "8232" if mode.endswith("elong") else ("27000" if mode.endswith("cfg4") else "8000"),   # 8232 = 2 * 4116 = 3 * 2744
            "DOM_BACKEND": "nccl" if mode.startswith("nccl") else "gloo"}
     port = 29511 + nproc + 10 * nvt + (20 if stage else 0) + {"sync": 0, "async": 40, "nccl-sync": 80, "nccl-async": 120,
                                                                 "nccl-native": 160, "nccl-native-prune": 200, "async-prune": 240, "async-prune-poly": 280,
-                                                                "sync-poly": 320, "async-prune-elong": 360, "async-elong": 400}[mode]
+                                                                "sync-poly": 320, "async-prune-elong": 360, "async-elong": 400,
+                                                                "shim-native": 440, "shim-native-prune": 480, "async-prune-cfg4": 520,
+                                                                "shim-native-prune-cfg4": 560}[mode]
     _launch(nproc, env, port)
+
+
+def test_slab_half_million_particles_per_rank():
+    """BASELINE configs[3]'s per-rank load (4,194,304 / 8 = 524,288 owned particles per GPU): two ranks, the
+    2^20-particle cube of the metric cut into two slabs of 52.7 (as bench.py --gpus 2 --scaling strong does), native
+    window loop with inner rows over the shared-memory transport; 60 steps against the single-handle run and the
+    oracle's forces."""
+    env = {"DOM_KT": "1.4737", "DOM_STEPS": "60", "DOM_NVT": "1", "MDHIP_DOM_STAGE": "device", "DOM_ASYNC": "native",
+           "MDHIP_RCCL_PATH": _build_shim(), "DOM_PRUNE": "1", "DOM_POLY": "0", "DOM_ELONG": "0", "DOM_N": "1048576",
+           "DOM_BACKEND": "gloo", "DOM_DT": "0.001"}
+    _launch(2, env, 29911)
