@@ -580,11 +580,11 @@ void rebuild_t(md_ctx *c)
         }
         c->have_nlist32 = true;
         if (c->allow_tiles) {
-            static bool attr_set2 = false;
+            static int attr_dev_mask2 = 0; // per device
             size_t lds = (size_t)MD_HT * 4 + (size_t)MD_HT * 2 + (MD_TILE + 1) * 4;
-            if (!attr_set2) {
+            if (!(attr_dev_mask2 & (1 << (c->device & 31)))) {
                 HIPCHK(hipFuncSetAttribute((const void *)k_tile_localize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                attr_set2 = true;
+                attr_dev_mask2 |= 1 << (c->device & 31);
             }
             k_tile_localize<<<c->nblk, MD_TILE, lds, st>>>(c->nlist.p, c->nlist16.p, c->maxn, c->nmax_tile.p,
                                                            (uint32_t)c->cap, c->halo.p, c->hcap, c->halo_count.p,
@@ -717,12 +717,12 @@ void launch_force_tpu(md_ctx *c, bool want_uw, bool kick, double dt, int step, i
                                                                      c->scal.p, step)
 #define LT(UW, KK, PR)                                                                                              \
     do {                                                                                                            \
-        static size_t attr_bytes = 0;                                                                               \
+        static int attr_dev_mask = 0; /* the attribute is per device: one bit per device id */                      \
         auto kfn = k_force_tile<D, POT, UNIFORM, UW, KK, PR>;                                                       \
-        if (c->tile_lds > attr_bytes) {                                                                             \
+        if (!(attr_dev_mask & (1 << (c->device & 31)))) {                                                           \
             HIPCHK(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,               \
                                        (int)(160 * 1024 - 2048)));                                                  \
-            attr_bytes = 160 * 1024;                                                                                \
+            attr_dev_mask |= 1 << (c->device & 31);                                                                 \
         }                                                                                                           \
         kfn<<<nb, MD_TILE, c->tile_lds, c->stream>>>(n, s, c->pp, rows16, c->maxn, rowmax, c->halo.p, c->hcap,      \
                                                      c->halo_count.p, dt, c->partials.p, nb, c->scal.p, step,       \

@@ -282,3 +282,13 @@ def test_julia_binding_matches_the_header():
     for name in ("run_simulation!", "minimize!", "fire_minimize!", "write_to_file_lammps", "traj_name", "log_times",
                  "compress", "Brownian", "evaluate(p::PseudoHS", "evaluate(p::Polydisperse"):
         assert name in src
+
+
+def test_triclinic_unit_cell_is_refused_through_initialize_state(tmp_path):
+    """src/boundary.jl:7-17 and src/initialization.jl:7-18 take any cell matrix; this version builds its cell grid for
+    diagonal (orthorhombic) cells only and says so -- through the reference-level entry point, not only md_create."""
+    params = md.Parameters(0.5, 64, 0.001, md.LennardJones())
+    cell = np.array([[12.0, 2.0, 0.0], [0.0, 12.0, 0.0], [0.0, 0.0, 12.0]])
+    x = np.random.default_rng(0).uniform(0, 10, (64, 3))
+    with pytest.raises(md.MdhipError, match="orthorhombic"):
+        md.initialize_state(params, str(tmp_path), cutoff=2.5, positions=x, diameters=np.ones(64), unitcell=cell)
