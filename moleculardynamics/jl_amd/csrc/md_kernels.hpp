@@ -861,118 +861,45 @@ __global__ void __launch_bounds__(MD_TILE)
 // The pair loop of the tiled kernels: one lane per particle walks its row of 16-bit LDS offsets, MD_UNROLL
 // candidates per iteration.  Shared by k_force_tile (forces at the stored positions) and k_step_tile (a whole
 // velocity-Verlet step).  PRUNE: the kept entries (d2 <= rin2) are appended to the lane's inner row as it goes.
-template <int D, int POT, bool UNIFORM, bool WANT_UW, bool PRUNE>
-__device__ __forceinline__ void tile_pair_loop(const unsigned char *smem, const ushort4 *row4,
-                                               ushort4 (&jn)[MD_UNROLL / 4], int m, int H,
-                                               const double4 &pi, const PotParams &pp, unsigned long long *rin64,
-                                               double rin2, unsigned long long &acc, int &cin, double &fx, double &fy,
-                                               double &fz, double &us, double &ws, const uint16_t *remap8 = nullptr)
+// One block of NQ candidates (NQ = 8 in the loop, 4 for a row's last half iteration): all LDS reads issued before
+// the first use, then the arithmetic.  o[q]: byte offsets of the candidates' records in the tile's LDS image.
+template <int D, int POT, bool UNIFORM, bool WANT_UW, bool PRUNE, int NQ>
+__device__ __forceinline__ void tile_pair_block(const unsigned char *smem, const unsigned (&o)[NQ], const double4 &pi,
+                                                const PotParams &pp, unsigned long long *rin64, double rin2,
+                                                unsigned long long &acc, int &cin, double &fx, double &fy, double &fz,
+                                                double &us, double &ws, const uint16_t *remap8)
 {
-    constexpr int RS = UNIFORM ? 24 : 32;
-    constexpr int G = MD_UNROLL / 4; // index groups per iteration; jn holds the first G groups, loaded by the caller
-    // Two index groups (8 candidates) per iteration: all their LDS reads are issued before the first
-    // use, which is what hides the LDS latency at 4 waves per SIMD.  The indices of the next pair of
-    // groups are fetched while this one is computed.  A row has a multiple of 4 entries; when the
-    // second group of the last pair does not exist its offsets are replaced by the sentinel record.
-    const unsigned sent_off = (unsigned)H * RS;
-    for (int r = 0; r < m; r += MD_UNROLL) {
-        unsigned o[MD_UNROLL];
+    double xj[NQ], yj[NQ], zj[NQ], wj[NQ];
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            bool has = r + 4 * g < m;
-            o[4 * g + 0] = has ? jn[g].x : sent_off;
-            o[4 * g + 1] = has ? jn[g].y : sent_off;
-            o[4 * g + 2] = has ? jn[g].z : sent_off;
-            o[4 * g + 3] = has ? jn[g].w : sent_off;
-        }
+    for (int q = 0; q < NQ; ++q) {
+        const double *rec = (const double *)(smem + o[q]);
+        xj[q] = rec[0];
+        yj[q] = rec[1];
+        if constexpr (D == 3) zj[q] = rec[2];
+        if constexpr (!UNIFORM) wj[q] = rec[3];
+    }
+    if constexpr (POT == POT_LJ && UNIFORM && !WANT_UW && D == 3) {
+        // LJ, one diameter, no energies: candidates in pairs share one reciprocal,
+        //   1/a = b * 1/(ab), 1/b = a * 1/(ab)   (masked d^2 = 2^511: the product stays finite),
+        // and the force uses the sigma-folded polynomial f/r = z^4 (A z^3 - B), z = 1/r^2.
+        double dxq[NQ], dyq[NQ], dzq[NQ], dm[NQ];
+        // Acceptance test.  The decision belongs to the reference-form distance d2_ref (no fma); the fma chain
+        // below differs from it by at most a few ulp, so its HIGH DWORD alone settles every candidate that is
+        // not within ~2^-20 (relative) of the cutoff: with t = hi(d2) - (hi(c2) - 1),
+        //     (int)t < 0 : surely inside      t > 2 : surely outside      t in {0,1,2} : undecided.
+        // One integer subtract and one integer compare per candidate instead of an fp64 compare; the rare
+        // undecided ones (2.6e-4 per particle and step at this density) are re-decided exactly below.
+        unsigned tmin = 0xffffffffu;
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-            int rg = r + MD_UNROLL + 4 * g;
-            jn[g] = row4[(size_t)(((rg < m) ? rg : 0) >> 2) * 64];
-        }
-        double xj[MD_UNROLL], yj[MD_UNROLL], zj[MD_UNROLL], wj[MD_UNROLL];
-#pragma unroll
-        for (int q = 0; q < MD_UNROLL; ++q) {
-            const double *rec = (const double *)(smem + o[q]);
-            xj[q] = rec[0];
-            yj[q] = rec[1];
-            if constexpr (D == 3) zj[q] = rec[2];
-            if constexpr (!UNIFORM) wj[q] = rec[3];
-        }
-        if constexpr (POT == POT_LJ && UNIFORM && !WANT_UW && D == 3) {
-            // LJ, one diameter, no energies: candidates in pairs share one reciprocal,
-            //   1/a = b * 1/(ab), 1/b = a * 1/(ab)   (masked d^2 = 2^511: the product stays finite),
-            // and the force uses the sigma-folded polynomial f/r = z^4 (A z^3 - B), z = 1/r^2.
-            double dxq[MD_UNROLL], dyq[MD_UNROLL], dzq[MD_UNROLL], dm[MD_UNROLL];
-            // Acceptance test.  The decision belongs to the reference-form distance d2_ref (no fma); the fma chain
-            // below differs from it by at most a few ulp, so its HIGH DWORD alone settles every candidate that is
-            // not within ~2^-20 (relative) of the cutoff: with t = hi(d2) - (hi(c2) - 1),
-            //     (int)t < 0 : surely inside      t > 2 : surely outside      t in {0,1,2} : undecided.
-            // One integer subtract and one integer compare per candidate instead of an fp64 compare; the rare
-            // undecided ones (2.6e-4 per particle and step at this density) are re-decided exactly below.
-            unsigned tmin = 0xffffffffu;
-#pragma unroll
-            for (int q = 0; q < MD_UNROLL; ++q) {
-                dxq[q] = xj[q] - pi.x;
-                dyq[q] = yj[q] - pi.y;
-                dzq[q] = zj[q] - pi.z;
-                double d2 = dxq[q] * dxq[q];
-                d2 = __builtin_fma(dyq[q], dyq[q], d2);
-                d2 = __builtin_fma(dzq[q], dzq[q], d2);
-                if constexpr (PRUNE) {
-                    if (d2 <= rin2) { // (padding entries are 1e100 away: they never survive)
-                        acc |= (unsigned long long)(remap8 ? (unsigned)remap8[o[q] >> 3] : o[q]) << (16 * (cin & 3)); // (inner halo: its own offsets)
-                        ++cin;
-                        if ((cin & 3) == 0) {
-                            rin64[(size_t)((cin >> 2) - 1) * 64] = acc;
-                            acc = 0ull;
-                        }
-                    }
-                }
-                int hi = __double2hiint(d2);
-                unsigned t = (unsigned)hi - pp.c2_k;
-                tmin = min(tmin, t);
-                hi = ((int)t < 0) ? hi : 0x5fe00000;
-                dm[q] = __hiloint2double(hi, __double2loint(d2));
-            }
-            if (__any(tmin <= 2u)) {
-#pragma unroll
-                for (int q = 0; q < MD_UNROLL; ++q) {
-                    double d2 = dxq[q] * dxq[q];
-                    d2 = __builtin_fma(dyq[q], dyq[q], d2);
-                    d2 = __builtin_fma(dzq[q], dzq[q], d2);
-                    unsigned t = (unsigned)__double2hiint(d2) - pp.c2_k;
-                    if (t <= 2u) {
-                        bool hit = d2_ref<3>(dxq[q], dyq[q], dzq[q]) < pp.c2;
-                        dm[q] = __hiloint2double(hit ? __double2hiint(d2) : 0x5fe00000, __double2loint(d2));
-                    }
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < MD_UNROLL; q += 2) {
-                double ip = md_rcp1(dm[q] * dm[q + 1]);
-                double z[2] = {dm[q + 1] * ip, dm[q] * ip};
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    double z2 = z[h] * z[h];
-                    double t = __builtin_fma(pp.ljA, z2 * z[h], -pp.ljB);
-                    double fpr = (z2 * z2) * t;
-                    fx = __builtin_fma(-fpr, dxq[q + h], fx);
-                    fy = __builtin_fma(-fpr, dyq[q + h], fy);
-                    fz = __builtin_fma(-fpr, dzq[q + h], fz);
-                }
-            }
-        } else
-#pragma unroll
-        for (int q = 0; q < MD_UNROLL; ++q) {
-            double dx = xj[q] - pi.x;
-            double dy = yj[q] - pi.y;
-            double dz = 0.0;
-            if constexpr (D == 3) dz = zj[q] - pi.z;
-            double d2 = d2_ref<D>(dx, dy, dz);
+        for (int q = 0; q < NQ; ++q) {
+            dxq[q] = xj[q] - pi.x;
+            dyq[q] = yj[q] - pi.y;
+            dzq[q] = zj[q] - pi.z;
+            double d2 = dxq[q] * dxq[q];
+            d2 = __builtin_fma(dyq[q], dyq[q], d2);
+            d2 = __builtin_fma(dzq[q], dzq[q], d2);
             if constexpr (PRUNE) {
                 if (d2 <= rin2) { // (padding entries are 1e100 away: they never survive)
-                    // four 16-bit entries of a row are one 8-byte word (row_off): write it when it is full
                     acc |= (unsigned long long)(remap8 ? (unsigned)remap8[o[q] >> 3] : o[q]) << (16 * (cin & 3)); // (inner halo: its own offsets)
                     ++cin;
                     if ((cin & 3) == 0) {
@@ -981,18 +908,109 @@ __device__ __forceinline__ void tile_pair_loop(const unsigned char *smem, const 
                     }
                 }
             }
-            bool hit = d2 < pp.c2;
-            double d2m = mask_d2(d2, hit);
-            double u = 0.0, fpr;
-            pair_eval<POT, UNIFORM, WANT_UW>(d2m, pi.w, UNIFORM ? 0.0 : wj[q], pp, u, fpr);
-            fx = __builtin_fma(-fpr, dx, fx);
-            fy = __builtin_fma(-fpr, dy, fy);
-            if constexpr (D == 3) fz = __builtin_fma(-fpr, dz, fz);
-            if constexpr (WANT_UW) {
-                us += u;
-                ws = __builtin_fma(fpr, hit ? d2 : 0.0, ws);
+            int hi = __double2hiint(d2);
+            unsigned t = (unsigned)hi - pp.c2_k;
+            tmin = min(tmin, t);
+            hi = ((int)t < 0) ? hi : 0x5fe00000;
+            dm[q] = __hiloint2double(hi, __double2loint(d2));
+        }
+        if (__any(tmin <= 2u)) {
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                double d2 = dxq[q] * dxq[q];
+                d2 = __builtin_fma(dyq[q], dyq[q], d2);
+                d2 = __builtin_fma(dzq[q], dzq[q], d2);
+                unsigned t = (unsigned)__double2hiint(d2) - pp.c2_k;
+                if (t <= 2u) {
+                    bool hit = d2_ref<3>(dxq[q], dyq[q], dzq[q]) < pp.c2;
+                    dm[q] = __hiloint2double(hit ? __double2hiint(d2) : 0x5fe00000, __double2loint(d2));
+                }
             }
         }
+#pragma unroll
+        for (int q = 0; q < NQ; q += 2) {
+            double ip = md_rcp1(dm[q] * dm[q + 1]);
+            double z[2] = {dm[q + 1] * ip, dm[q] * ip};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                double z2 = z[h] * z[h];
+                double t = __builtin_fma(pp.ljA, z2 * z[h], -pp.ljB);
+                double fpr = (z2 * z2) * t;
+                fx = __builtin_fma(-fpr, dxq[q + h], fx);
+                fy = __builtin_fma(-fpr, dyq[q + h], fy);
+                fz = __builtin_fma(-fpr, dzq[q + h], fz);
+            }
+        }
+    } else
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        double dx = xj[q] - pi.x;
+        double dy = yj[q] - pi.y;
+        double dz = 0.0;
+        if constexpr (D == 3) dz = zj[q] - pi.z;
+        double d2 = d2_ref<D>(dx, dy, dz);
+        if constexpr (PRUNE) {
+            if (d2 <= rin2) { // (padding entries are 1e100 away: they never survive)
+                // four 16-bit entries of a row are one 8-byte word (row_off): write it when it is full
+                acc |= (unsigned long long)(remap8 ? (unsigned)remap8[o[q] >> 3] : o[q]) << (16 * (cin & 3)); // (inner halo: its own offsets)
+                ++cin;
+                if ((cin & 3) == 0) {
+                    rin64[(size_t)((cin >> 2) - 1) * 64] = acc;
+                    acc = 0ull;
+                }
+            }
+        }
+        bool hit = d2 < pp.c2;
+        double d2m = mask_d2(d2, hit);
+        double u = 0.0, fpr;
+        pair_eval<POT, UNIFORM, WANT_UW>(d2m, pi.w, UNIFORM ? 0.0 : wj[q], pp, u, fpr);
+        fx = __builtin_fma(-fpr, dx, fx);
+        fy = __builtin_fma(-fpr, dy, fy);
+        if constexpr (D == 3) fz = __builtin_fma(-fpr, dz, fz);
+        if constexpr (WANT_UW) {
+            us += u;
+            ws = __builtin_fma(fpr, hit ? d2 : 0.0, ws);
+        }
+    }
+}
+
+template <int D, int POT, bool UNIFORM, bool WANT_UW, bool PRUNE>
+__device__ __forceinline__ void tile_pair_loop(const unsigned char *smem, const ushort4 *row4,
+                                               ushort4 (&jn)[MD_UNROLL / 4], int m_lane, int H,
+                                               const double4 &pi, const PotParams &pp, unsigned long long *rin64,
+                                               double rin2, unsigned long long &acc, int &cin, double &fx, double &fy,
+                                               double &fz, double &us, double &ws, const uint16_t *remap8 = nullptr)
+{
+    constexpr int G = MD_UNROLL / 4; // index groups per iteration; jn holds the first G groups, loaded by the caller
+    static_assert(G == 2, "the tail handling below assumes two groups per iteration");
+    (void)H;
+    // The row length is the wave's (rows are padded to the wave maximum, a multiple of 4): scalar loop control.  Full
+    // iterations take two index groups (8 candidates); a row of 8 k + 4 entries ends with one 4-candidate block, so
+    // no lane ever evaluates a padding slot that is not in the row.  The index groups of the next iteration are
+    // fetched while this one is computed.
+    const int m = __builtin_amdgcn_readfirstlane(m_lane);
+    int r = 0;
+    for (; r + MD_UNROLL <= m; r += MD_UNROLL) {
+        unsigned o[MD_UNROLL];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            o[4 * g + 0] = jn[g].x;
+            o[4 * g + 1] = jn[g].y;
+            o[4 * g + 2] = jn[g].z;
+            o[4 * g + 3] = jn[g].w;
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            int rg = r + MD_UNROLL + 4 * g; // (past the end: any valid group, never used)
+            jn[g] = row4[(size_t)(((rg < m) ? rg : 0) >> 2) * 64];
+        }
+        tile_pair_block<D, POT, UNIFORM, WANT_UW, PRUNE, MD_UNROLL>(smem, o, pi, pp, rin64, rin2, acc, cin, fx, fy, fz, us,
+                                                                     ws, remap8);
+    }
+    if (r < m) {
+        unsigned o[4] = {jn[0].x, jn[0].y, jn[0].z, jn[0].w};
+        tile_pair_block<D, POT, UNIFORM, WANT_UW, PRUNE, 4>(smem, o, pi, pp, rin64, rin2, acc, cin, fx, fy, fz, us, ws,
+                                                            remap8);
     }
 }
 
