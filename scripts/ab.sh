@@ -3,7 +3,7 @@
 cd $GRAFT_REPO_ROOT
 D=moleculardynamics/jl_amd/csrc
 for rep in 1 2 3; do
-  for v in A B; do
+  for v in ${VARIANTS:-A B}; do
     cp $D/libmdhip_$v.so $D/libmdhip.so
     python bench.py --no-cpu-baseline "$@" > gpurun_out/ab_$v.json 2>/dev/null
     python -c "

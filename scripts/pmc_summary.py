@@ -7,7 +7,7 @@ for f in files:
         name = row['Kernel_Name'].split('(')[0][:60]
         agg[name][row['Counter_Name']].append(float(row['Counter_Value']))
 for name, ctrs in sorted(agg.items()):
-    if not any(k in name for k in ('k_force', 'k_build', 'k_kickdrift')):
+    if not any(k in name for k in ('k_force', 'k_step', 'k_build', 'k_kickdrift', 'k_finalize')):
         continue
     print(name)
     for c, v in sorted(ctrs.items()):

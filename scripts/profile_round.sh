@@ -1,0 +1,31 @@
+#!/bin/bash
+# usage (on the GPU box): bash scripts/profile_round.sh r02   -- the round's evidence set, written under gpurun_out/prof_<tag>/
+set -e
+tag=${1:-rXX}
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/prof_$tag
+mkdir -p $O
+cd $R
+python bench.py --steps 200 --warmup 50 > $O/bench_n1.json 2> $O/bench_n1.err
+echo "bench 200 done"
+python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_n1_driver_cmd.json 2> $O/bench_n1_driver_cmd.err
+echo "bench 20 done"
+python bench.py --gpus 1 --config 4 --steps 100 --warmup 20 --no-cpu-baseline > $O/bench_config4_n1.json 2> $O/bench_config4_n1.err
+echo "bench config4 done"
+MDHIP_BENCH_DOMAIN=1 python bench.py --steps 200 --warmup 50 --no-cpu-baseline > $O/bench_slab_path_world1_rccl.json 2> $O/bench_slab.err || echo "slab path bench failed"
+echo "bench slab done"
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks -- python3 $R/bench.py --no-cpu-baseline --steps 400 --warmup 50 > $O/ks.log 2>&1
+cp $(ls $O/ks/*/*kernel_stats.csv | head -1) $O/kernel_stats.csv
+echo "kernel stats done"
+i=0
+for ctrs in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS" "GRBM_GUI_ACTIVE"; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $O/pmc_$i -- python3 $R/bench.py --steps 20 --warmup 5 --equil 60 --no-cpu-baseline > $O/pmc_$i.log 2>&1
+  python3 $R/scripts/pmc_summary.py $O/pmc_$i >> $O/pmc_summary.txt
+  echo "pmc pass $i done"
+done
+cd $R
+python3 scripts/make_traffic_json.py $O/pmc_summary.txt $O/traffic_k_step_tile.json
+rm -rf $O/ks $O/pmc_[0-9]
+echo "profile set complete"
