@@ -872,7 +872,10 @@ __device__ __forceinline__ void tile_pair_block(const unsigned char *smem, const
     double xj[NQ], yj[NQ], zj[NQ], wj[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-        const double *rec = (const double *)(smem + o[q]);
+        // (volatile: three separate ds_read_b64.  Left alone the compiler merges x and y into one ds_read2_b64, which
+        // the LDS serves as two 4 x 16-lane passes -- 8 array cycles against 2 + 2 for two plain 8-byte reads)
+        typedef const volatile __attribute__((address_space(3))) double lds_cvd;
+        lds_cvd *rec = (lds_cvd *)(smem + o[q]);
         xj[q] = rec[0];
         yj[q] = rec[1];
         if constexpr (D == 3) zj[q] = rec[2];

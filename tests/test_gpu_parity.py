@@ -291,10 +291,10 @@ def test_full_size_vs_oracle_cells(oracle, n):
 
 def test_config4_4m_particles_on_one_gpu(oracle):
     """BASELINE configs[3]: N = 4,194,304, rho = 0.897 (L = 167.22), NVE -- the whole system on ONE handle (~8 GB):
-    forces / U / W / accepted-pair count against the oracle's linked-cell path, Newton's third law, and 20 NVE steps
+    forces / U / W / accepted-pair count against the oracle's linked-cell path, Newton's third law, and 12 NVE steps
     (fused step loop, prune steps and at least the initial list build at this size) against oracle.run."""
     from moleculardynamics.jl_amd import MDDevice
-    n, nsteps, dt = 4194304, 20, 0.001
+    n, nsteps, dt = 4194304, 12, 0.001
     s = lj_system(n)
     assert abs(s["box"][0] - 167.2204) < 1e-3
     pot = oracle.make_pot(0, LJ)
