@@ -1054,13 +1054,115 @@ __device__ __forceinline__ void tile_prune_tail(DevState &s, Scalars *sc, int H 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Inner halo (prune steps).  The ordinary steps that follow a prune step stage only the halo particles within
+// (cutoff + inner skin) of the box around the tile's own particles -- every entry an inner row can hold points there --
+// about 2/3 of the outer halo: a third less staging traffic and a smaller LDS image.  Here: box of the own positions,
+// one clamped-distance test per staged record, an ordered block scan that numbers the kept records, the inner halo
+// list, and a table (old offset >> 3) -> new offset that the row append applies.  Returns the number of kept records
+// (the inner image's sentinel slot); *remap_out = the table (in LDS behind the halo image).
+// Contains barriers: call from uniform control flow, after the halo image is complete.
+// ------------------------------------------------------------------------------------------
+template <int D, bool UNIFORM>
+__device__ __forceinline__ int tile_inner_halo(unsigned char *smem, int H, const uint32_t *hl, int bid, const double4 &pi,
+                                               bool active, double rin2, uint32_t *__restrict__ halo_in, int hcap_in,
+                                               int32_t *__restrict__ halo_in_count, Scalars *sc, int step,
+                                               const uint16_t **remap_out)
+{
+    constexpr int RS = UNIFORM ? 24 : 32;
+    __shared__ double sh_bb[MD_TILE / 64][6];
+    __shared__ int sh_scan2[16];
+    __shared__ int sh_hin;
+    const int lane = threadIdx.x & 63;
+    uint16_t *rm = (uint16_t *)(smem + ((((size_t)(H + 1) * RS) + 15) & ~(size_t)15));
+    const double big = 1.0e300;
+    const double xn[3] = {pi.x, pi.y, pi.z};
+    double lo3[3], hi3[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        double v = (c < D) ? xn[c] : 0.0;
+        lo3[c] = -wave_max_d((active && c < D) ? -v : -big);
+        hi3[c] = wave_max_d((active && c < D) ? v : -big);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            sh_bb[threadIdx.x >> 6][c] = lo3[c];
+            sh_bb[threadIdx.x >> 6][3 + c] = hi3[c];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        lo3[c] = big;
+        hi3[c] = -big;
+        for (int w = 0; w < MD_TILE / 64; ++w) {
+            lo3[c] = fmin(lo3[c], sh_bb[w][c]);
+            hi3[c] = fmax(hi3[c], sh_bb[w][3 + c]);
+        }
+    }
+    int carry = 0;
+    for (int h0 = 0; h0 < H; h0 += 8 * MD_TILE) {
+        // thread t owns 8 CONSECUTIVE slots: the scan keeps the halo order
+        const int hb = h0 + 8 * (int)threadIdx.x;
+        unsigned near = 0u;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int h = hb + i;
+            if (h < H) {
+                const double *rec = (const double *)(smem + (size_t)h * RS);
+                double dd = 0.0;
+#pragma unroll
+                for (int c = 0; c < D; ++c) {
+                    double xc = rec[c];
+                    double dl = fmax(fmax(lo3[c] - xc, xc - hi3[c]), 0.0);
+                    dd = __builtin_fma(dl, dl, dd);
+                }
+                if (dd <= rin2) near |= 1u << i;
+            }
+        }
+        int tot;
+        int base = carry + block_excl_scan(__popc(near), sh_scan2, &tot);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int h = hb + i;
+            if (h < H) {
+                bool nr = (near >> i) & 1u;
+                // (a record that is not kept can not be referenced by a kept entry)
+                rm[((unsigned)h * RS) >> 3] = nr ? (uint16_t)((unsigned)base * RS) : (uint16_t)0xffffu;
+                if (nr) {
+                    if (base < hcap_in) halo_in[(size_t)bid * hcap_in + base] = hl[h];
+                    ++base;
+                }
+            }
+        }
+        carry += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        sh_hin = carry;
+        halo_in_count[bid] = carry;
+        if (carry > hcap_in || (size_t)(carry + 1) * RS > 65535) {
+            // does not fit the ordinary steps' LDS image.  THIS step is unaffected (its forces come from the outer rows
+            // and the full image); the steps behind it were enqueued on the inner rows, so they are stopped: the
+            // "violation" is recorded for the next step, the host turns the inner halo off and prunes again there.
+            atomicOr(&sc->halo_overflow, 16);
+            atomicMin(&sc->first_viol, step + 1);
+        }
+    }
+    __syncthreads();
+    *remap_out = rm;
+    return sh_hin;
+}
+
 template <int D, int POT, bool UNIFORM, bool WANT_UW, bool KICK, bool PRUNE>
 __global__ void __launch_bounds__(MD_TILE)
     k_force_tile(int n, DevState s, PotParams pp, const uint16_t *__restrict__ nlist16, int maxn,
                  const int32_t *__restrict__ nmax_tile, const uint32_t *__restrict__ halo, int hcap,
                  const int32_t *__restrict__ halo_count, double dt, double *__restrict__ partials, int nblk_total,
                  Scalars *__restrict__ sc, int step, uint16_t *__restrict__ rows_in, int32_t *__restrict__ nmax_in,
-                 double rin2, long long *__restrict__ stamps = nullptr)
+                 double rin2, long long *__restrict__ stamps = nullptr, uint32_t *__restrict__ halo_in = nullptr,
+                 int hcap_in = 0, int32_t *__restrict__ halo_in_count = nullptr)
 {
 #define MD_SSTAMP(i)                                                                                   \
     do {                                                                                               \
@@ -1145,10 +1247,18 @@ __global__ void __launch_bounds__(MD_TILE)
     MD_SSTAMP(2);
     __syncthreads();
     MD_SSTAMP(3);
+    // prune step with an inner halo (see tile_inner_halo)
+    const uint16_t *remap8 = nullptr;
+    int Hsent = H;
+    if constexpr (PRUNE) {
+        if (halo_in)
+            Hsent = tile_inner_halo<D, UNIFORM>(smem, H, hl, bid, pi, active, rin2, halo_in, hcap_in, halo_in_count, sc, step,
+                                                &remap8);
+    }
     double fx = 0.0, fy = 0.0, fz = 0.0, us = 0.0, ws = 0.0;
-    tile_pair_loop<D, POT, UNIFORM, WANT_UW, PRUNE>(smem, row4, jn, m, H, pi, pp, rin64, rin2, acc, cin, fx, fy, fz, us, ws);
+    tile_pair_loop<D, POT, UNIFORM, WANT_UW, PRUNE>(smem, row4, jn, m, H, pi, pp, rin64, rin2, acc, cin, fx, fy, fz, us, ws, remap8);
     MD_SSTAMP(4);
-    if constexpr (PRUNE) tile_prune_tail<D, UNIFORM>(s, sc, H, k, active, lane, wt, pi, rin64, nmax_in, acc, cin);
+    if constexpr (PRUNE) tile_prune_tail<D, UNIFORM>(s, sc, Hsent, k, active, lane, wt, pi, rin64, nmax_in, acc, cin);
     double ke = 0.0;
     if (active) {
         s.f[0][k] = fx;
@@ -1351,96 +1461,13 @@ __global__ void __launch_bounds__(MD_TILE)
     MD_SSTAMP(2);
     __syncthreads();
     MD_SSTAMP(3);
-    // Prune step with an inner halo: the ordinary steps that follow stage only the halo particles within
-    // (cutoff + inner skin) of the box around the tile's own particles -- every entry an inner row can hold points
-    // there -- about 2/3 of the outer halo: a third less staging traffic and a smaller LDS image (more resident
-    // blocks).  Here: box of the own positions, one clamped-distance test per staged record, an ordered block scan
-    // that numbers the kept records, the inner halo list, and a table old offset -> new offset that the row
-    // append below applies.
+    // prune step with an inner halo (see tile_inner_halo)
     const uint16_t *remap8 = nullptr;
     int Hsent = H;
     if constexpr (PRUNE) {
-        if (halo_in) {
-            __shared__ double sh_bb[MD_TILE / 64][6];
-            __shared__ int sh_scan2[16];
-            __shared__ int sh_hin;
-            uint16_t *rm = (uint16_t *)(smem + ((((size_t)(H + 1) * RS) + 15) & ~(size_t)15));
-            const double big = 1.0e300;
-            double lo3[3], hi3[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                double v = (c < D) ? xn[c] : 0.0;
-                lo3[c] = -wave_max_d((active && c < D) ? -v : -big);
-                hi3[c] = wave_max_d((active && c < D) ? v : -big);
-            }
-            if (lane == 0) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    sh_bb[threadIdx.x >> 6][c] = lo3[c];
-                    sh_bb[threadIdx.x >> 6][3 + c] = hi3[c];
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                lo3[c] = big;
-                hi3[c] = -big;
-                for (int w = 0; w < MD_TILE / 64; ++w) {
-                    lo3[c] = fmin(lo3[c], sh_bb[w][c]);
-                    hi3[c] = fmax(hi3[c], sh_bb[w][3 + c]);
-                }
-            }
-            int carry = 0;
-            for (int h0 = 0; h0 < H; h0 += 8 * MD_TILE) {
-                // thread t owns 8 CONSECUTIVE slots: the scan keeps the halo order
-                const int hb = h0 + 8 * (int)threadIdx.x;
-                unsigned near = 0u;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    int h = hb + i;
-                    if (h < H) {
-                        const double *rec = (const double *)(smem + (size_t)h * RS);
-                        double dd = 0.0;
-#pragma unroll
-                        for (int c = 0; c < D; ++c) {
-                            double xc = rec[c];
-                            double dl = fmax(fmax(lo3[c] - xc, xc - hi3[c]), 0.0);
-                            dd = __builtin_fma(dl, dl, dd);
-                        }
-                        if (dd <= rin2) near |= 1u << i;
-                    }
-                }
-                int tot;
-                int base = carry + block_excl_scan(__popc(near), sh_scan2, &tot);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    int h = hb + i;
-                    if (h < H) {
-                        bool nr = (near >> i) & 1u;
-                        // (a record that is not kept can not be referenced by a kept entry; point it at the sentinel)
-                        rm[((unsigned)h * RS) >> 3] = nr ? (uint16_t)((unsigned)base * RS) : (uint16_t)0xffffu;
-                        if (nr) {
-                            if (base < hcap_in) halo_in[(size_t)bid * hcap_in + base] = hl[h];
-                            ++base;
-                        }
-                    }
-                }
-                carry += tot;
-                __syncthreads();
-            }
-            if (threadIdx.x == 0) {
-                sh_hin = carry;
-                halo_in_count[bid] = carry;
-                if (carry > hcap_in || (size_t)(carry + 1) * RS > 65535) {
-                    // does not fit the ordinary steps' LDS image: the host turns the inner halo off and redoes the step
-                    atomicOr(&sc->halo_overflow, 16);
-                    atomicMin(&sc->first_viol, step);
-                }
-            }
-            __syncthreads();
-            Hsent = sh_hin;
-            remap8 = rm;
-        }
+        if (halo_in)
+            Hsent = tile_inner_halo<D, UNIFORM>(smem, H, hl, bid, pi, active, rin2, halo_in, hcap_in, halo_in_count, sc, step,
+                                                &remap8);
     }
     double fx = 0.0, fy = 0.0, fz = 0.0, us = 0.0, ws = 0.0;
     tile_pair_loop<D, POT, UNIFORM, WANT_UW, PRUNE>(smem, row4, jn, m, H, pi, pp, rin64, rin2, acc, cin, fx, fy, fz, us, ws, remap8);

@@ -270,6 +270,7 @@ __global__ void k_reset_flags(Scalars *sc)
 }
 
 __global__ void k_reset_disp0(Scalars *sc) { sc->max_disp2_bits = 0ull; }
+__global__ void k_clear_halo_overflow(Scalars *sc) { sc->halo_overflow = 0; }
 
 // before a prune step: the displacement maximum since the build is recomputed by that step
 // (skipped, like the step itself, when an earlier step of the window recorded a violation)
@@ -634,6 +635,7 @@ void rebuild_t(md_ctx *c)
         // (uniform: 4 x 40 KB; per-particle diameters: 3 x 53 KB), never more than the outer halo itself
         const size_t target = (c->tile_rs == 24) ? (40 * 1024 - 256) : (53 * 1024);
         int cap_in = (int)std::min<size_t>((size_t)c->hstride, target / c->tile_rs - 1);
+        if (c->dom.on) cap_in = c->hstride; // (a slab handle's prune step must not fail: see launch_force_tpu)
         c->hcap_in = std::max(cap_in, 1);
         c->tile_lds_in = (((size_t)(c->hcap_in + 1) * c->tile_rs) + 15) & ~(size_t)15;
         c->halo_in.ensure((size_t)c->nblk * c->hcap_in);
@@ -702,9 +704,32 @@ void launch_force_tpu(md_ctx *c, bool want_uw, bool kick, double dt, int step, i
     bool prune_step = rows == 0 && c->prune_on && !c->inner_valid && kick;
     // (inner rows written by a fused prune step index the INNER halo image, which this kernel does not stage: the
     // outer rows serve instead -- a superset, valid as long as the list is)
-    bool use_inner = rows == 0 && c->inner_valid && !c->inner_halo_live;
+    // (inner rows whose offsets index the inner halo image need that image staged: every launch through here
+    // knows which of the two the current inner rows belong to -- inner_halo_live)
+    bool use_inner = rows == 0 && c->inner_valid;
     const uint16_t *rows16 = use_inner ? c->nlist16_in.p : c->nlist16.p;
     const int32_t *rowmax = use_inner ? c->nmax_tile_in.p : c->nmax_tile.p;
+    // Inner halo on the classic path.  A slab handle must not fail a prune step from inside the force kernel (its
+    // violation flag is all-reduced BEFORE the force kernel of a step): there the inner halo gets the outer halo's
+    // capacity -- it can not overflow -- and only the staging traffic shrinks, not the LDS image.
+    const bool ih = c->allow_inner_halo && c->prune_on && c->hcap_in > 0 && c->use_tiles;
+    const uint32_t *halo_p = c->halo.p;
+    int halo_cap = c->hcap;
+    const int32_t *halo_cnt = c->halo_count.p;
+    size_t lds_bytes = c->tile_lds;
+    uint32_t *hin_p = nullptr;
+    if (prune_step && ih) {
+        hin_p = c->halo_in.p;
+        lds_bytes = ((c->tile_lds + 15) & ~(size_t)15) + (c->tile_lds / 8 + 8) * 2; // + the offset translation table
+        c->inner_halo_live = true;
+    } else if (prune_step) {
+        c->inner_halo_live = false;
+    } else if (use_inner && c->inner_halo_live) {
+        halo_p = c->halo_in.p;
+        halo_cap = c->hcap_in;
+        halo_cnt = c->halo_in_count.p;
+        lds_bytes = c->tile_lds_in;
+    }
     DevState s = c->dev(c->cur);
     double rin = c->rc + c->inner_skin;
     if (prune_step) {
@@ -724,10 +749,10 @@ void launch_force_tpu(md_ctx *c, bool want_uw, bool kick, double dt, int step, i
                                        (int)(160 * 1024 - 2048)));                                                  \
             attr_dev_mask |= 1 << (c->device & 31);                                                                 \
         }                                                                                                           \
-        kfn<<<nb, MD_TILE, c->tile_lds, c->stream>>>(n, s, c->pp, rows16, c->maxn, rowmax, c->halo.p, c->hcap,      \
-                                                     c->halo_count.p, dt, c->partials.p, nb, c->scal.p, step,       \
-                                                     c->nlist16_in.p, c->nmax_tile_in.p, rin * rin,                 \
-                                                     c->dbg_stamps.p);                                              \
+        kfn<<<nb, MD_TILE, lds_bytes, c->stream>>>(n, s, c->pp, rows16, c->maxn, rowmax, halo_p, halo_cap,          \
+                                                   halo_cnt, dt, c->partials.p, nb, c->scal.p, step,                \
+                                                   c->nlist16_in.p, c->nmax_tile_in.p, rin * rin,                   \
+                                                   c->dbg_stamps.p, hin_p, c->hcap_in, c->halo_in_count.p);         \
     } while (0)
     prof_begin(c);
     if (prune_step && c->prof_open) c->prof_prune_acc++;
@@ -791,7 +816,11 @@ void launch_force_custom(md_ctx *c, int dim, bool want_uw, bool kick, double dt,
         int32_t *nin = nullptr;
         double rin2 = 0.0;
         long long *stamps = nullptr;
-        void *args[] = {&n, &s, &c->pp, &l16, &maxn, &nmt, &halo, &hcap, &hc, &dt, &part, &nb, &sc, &step, &rin, &nin, &rin2, &stamps};
+        uint32_t *hin = nullptr;
+        int hcap_in = 0;
+        int32_t *hinc = nullptr;
+        void *args[] = {&n, &s, &c->pp, &l16, &maxn, &nmt, &halo, &hcap, &hc, &dt, &part, &nb, &sc, &step, &rin, &nin, &rin2, &stamps,
+                        &hin, &hcap_in, &hinc};
         HIPCHK(hipModuleLaunchKernel(c->rtc->tile[dim - 2][want_uw][kick], nb, 1, 1, MD_TILE, 1, 1,
                                      (unsigned)c->tile_lds, c->stream, args, nullptr));
     } else {
@@ -1773,6 +1802,14 @@ int md_run(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, double tau, dou
         uwk[0] = h.U;
         uwk[1] = h.W;
         uwk[2] = h.K;
+    }
+    if (h.halo_overflow & 16) {
+        // the LAST step's prune found an inner halo that does not fit: nothing ran on those rows; drop them
+        ctx->allow_inner_halo = false;
+        ctx->inner_valid = false;
+        k_reset_viol<<<1, 1, 0, st>>>(ctx->scal.p);
+        k_clear_halo_overflow<<<1, 1, 0, st>>>(ctx->scal.p);
+        HIPCHK(hipStreamSynchronize(st));
     }
     ctx->st_steps += nsteps;
     API_END
