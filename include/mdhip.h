@@ -239,7 +239,12 @@ int md_dom_comm_unique_id(const char *rccl_path, void *id128);
 int md_dom_comm_init(md_ctx *ctx, const char *rccl_path, const void *id128);
 int md_dom_run_window(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, double tau, double nf, const double *ktemp,
                       const double *r1, const double *r2, int report_last, int apply_pending_scale,
-                      int64_t prune_interval, int32_t *first_viol, double *uwk, double *info /* [6] or NULL */);
+                      int64_t prune_interval, int32_t *first_viol, double *uwk, double *info /* [7] or NULL */);
+/* On tiled handles md_dom_run_window runs the FUSED step (csrc/md_domain.hpp: one step kernel + two small launches and two
+ * collectives per step; what travels is the boundary particles' state records).  Then info[6] = 1 and, after a violation,
+ * the state returned is that of the last complete step first_viol - 1: the caller refreshes the rows and resumes AT step
+ * first_viol (no md_dom_forces call).  info[6] = 0: the classic sequence ran -- the violating step's drift is applied and
+ * md_dom_forces completes it.                                                                                   */
 /* Inner rows (see md_set_inner_skin) on a slab handle.  Every rank must prune at the same steps, so the caller
  * plans the schedule from all-reduced quantities: prune_interval (md_dom_async_begin / md_dom_run_window) = steps
  * between prune steps inside a window (0 = none scheduled); info (md_dom_async_end / md_dom_run_window) returns {1 if the violating step was a prune step, this rank's d1 = max|x - x0| at

@@ -329,3 +329,120 @@ __global__ void k_dom_global_finalize(const double *__restrict__ sums, int want_
     sc->K = K;
     sc->T = 2.0 * K / nf;
 }
+
+// ------------------------------------------------------------------------------------------
+// Fused slab step (md_dom_run_window on tiled handles): the step kernel k_step_tile computes the positions of the
+// halo particles itself, from their (p, v') state records, so what travels to the neighbours after step t is the
+// RECORD of every boundary particle (6 doubles, p translated across the global periodic face) instead of its
+// coordinates, and nothing has to be exchanged between a drift and a force evaluation:
+//     k_step_tile(t)  ->  k_dom_post(t)  ->  all-reduce {sum v'^2, U, W, violated}  ->  send/recv records
+//                     ->  k_dom_adopt(t)  (records into the x-halo slots; violation adopted globally, or the
+//                         global K / U / W and the Bussi scale of step t formed: src/thermostat.jl:36-40)
+// Two small launches and two collectives per step instead of four launches and three collectives.
+// ------------------------------------------------------------------------------------------
+// block 0: this rank's fixed-order sums + its violation indicator; blocks >= 1: pack the boundary particles' records
+__global__ void __launch_bounds__(MD_BLOCK)
+    k_dom_post(int nblk, const double *__restrict__ partials, int want_uw, double *__restrict__ kuw4, const Scalars *sc,
+               int step, int n0, int n1, const int32_t *__restrict__ slot0, const int32_t *__restrict__ slot1,
+               const double2 *__restrict__ rec, size_t rstride, double shift0, double shift1,
+               double *__restrict__ out0, double *__restrict__ out1)
+{
+    const int fv = sc->first_viol;
+    if (blockIdx.x == 0) {
+        __shared__ double red[16];
+        double a = 0.0, b = 0.0, c = 0.0;
+        if (!(fv < step)) {
+            for (int i = threadIdx.x; i < nblk; i += blockDim.x) {
+                a += partials[i];
+                if (want_uw) {
+                    b += partials[nblk + i];
+                    c += partials[2 * nblk + i];
+                }
+            }
+        }
+        a = block_sum(a, red);
+        b = block_sum(b, red);
+        c = block_sum(c, red);
+        if (threadIdx.x == 0) {
+            kuw4[0] = a;
+            kuw4[1] = b;
+            kuw4[2] = c;
+            kuw4[3] = (fv == step) ? 1.0 : 0.0; // this rank's displacement check failed in this step
+        }
+        return;
+    }
+    if (fv < step) return; // (an earlier step was violated: this one did not run)
+    int j = (blockIdx.x - 1) * blockDim.x + threadIdx.x;
+    const int32_t *slot = slot0;
+    double *out = out0;
+    double shift = shift0;
+    if (j >= n0) {
+        j -= n0;
+        if (j >= n1) return;
+        slot = slot1;
+        out = out1;
+        shift = shift1;
+    }
+    const size_t k = (size_t)slot[j];
+    double2 a0 = rec[k], a1 = rec[rstride + k], a2 = rec[2 * rstride + k];
+    double *o = out + 6 * (size_t)j;
+    o[0] = a0.x + shift;
+    o[1] = a0.y;
+    o[2] = a1.x;
+    o[3] = a1.y;
+    o[4] = a2.x;
+    o[5] = a2.y;
+}
+
+__global__ void __launch_bounds__(MD_BLOCK)
+    k_dom_adopt(int n0, int n1, const int32_t *__restrict__ xh_slot, const double *__restrict__ in0,
+                const double *__restrict__ in1, double2 *__restrict__ rec, size_t rstride, int planes,
+                const double4 *__restrict__ pos, const double *__restrict__ kuw4, int want_uw, int nvt, double nf,
+                double term1, const double *__restrict__ kt, const double *__restrict__ r1,
+                const double *__restrict__ r2, Scalars *sc, int step, int finalize)
+{
+    const int fv = sc->first_viol; // (thread 0 may set it to `step` below: either value reads the same here)
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j == 0 && finalize && !(fv < step)) {
+        if (kuw4[3] > 0.0) {
+            if (step < sc->first_viol) sc->first_viol = step; // some rank's check failed: every rank stops here
+        } else {
+            double K = kuw4[0] / 2.0;
+            if (want_uw) {
+                sc->U = kuw4[1] / 2.0; // every pair was evaluated from both ends
+                sc->W = kuw4[2] / 2.0;
+            }
+            if (nvt) {
+                double tc = 2.0 * K / nf;
+                double rr1 = r1[step], rr2 = r2[step];
+                double c2 = (1.0 - term1) * kt[step] / (tc * nf);
+                double term_2 = c2 * (rr2 + rr1 * rr1);
+                double term_3 = 2.0 * rr1 * sqrt(term1 * c2);
+                double scale = sqrt(term1 + term_2 + term_3);
+                sc->scale = scale;
+                K = K * scale * scale;
+            }
+            sc->K = K;
+            sc->T = 2.0 * K / nf;
+        }
+    }
+    if (fv < step) return; // (this step did not run: its buffer set is the state to fall back to -- leave it alone)
+    if (j >= n0 + n1) return;
+    const double *in = j < n0 ? in0 + 6 * (size_t)j : in1 + 6 * (size_t)(j - n0);
+    const size_t k = (size_t)xh_slot[j];
+    rec[k] = make_double2(in[0], in[1]);
+    rec[rstride + k] = make_double2(in[2], in[3]);
+    rec[2 * rstride + k] = make_double2(in[4], in[5]);
+    if (planes > 3) rec[3 * rstride + k] = make_double2(pos[k].w, 0.0);
+}
+
+// after the fused window's buffer sets changed roles: the x-halo slots of the position array now in use take the
+// entries (diameters; coordinates as of the last build) the other array holds
+__global__ void __launch_bounds__(MD_BLOCK)
+    k_dom_copy_xhalo(int ntot, const int32_t *__restrict__ xh_slot, const double4 *__restrict__ from, double4 *__restrict__ to)
+{
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ntot) return;
+    const size_t k = (size_t)xh_slot[j];
+    to[k] = from[k];
+}

@@ -26,6 +26,7 @@
 #include "md_rccl.hpp"
 
 static RcclApi g_rccl;
+static const bool g_dom_group_flag = [] { const char *e = getenv("MDHIP_DOM_GROUP_FLAG"); return e && e[0] == '1'; }();
 
 namespace {
 
@@ -934,25 +935,29 @@ bool fused_uniform(md_ctx *c)
     return c->uniform_sigma && c->pot_kind != POT_POLYDISPERSE && c->pot_kind != POT_LJ_MOD;
 }
 
+// plane stride of the state records: owned particles only on a single-GPU handle; a slab handle also keeps the
+// records of the x-halo particles (slots behind the owned range) that its neighbours send every step
+inline size_t rec_stride(md_ctx *c) { return c->dom.on ? (size_t)c->cap + 1 : (size_t)c->ncap; }
+
 // canonical state arrays -> records of buffer set 0
 void fused_enter(md_ctx *c, double dt)
 {
     int n = (int)c->n;
     const bool uni = fused_uniform(c);
     const size_t planes = uni ? 3 : 4;
-    for (int w = 0; w < 2; ++w) c->rec[w].ensure((size_t)c->ncap * planes);
+    for (int w = 0; w < 2; ++w) c->rec[w].ensure(rec_stride(c) * planes);
     DevState s = c->dev(c->cur);
     double h2 = (dt * dt) / 2.0;
     if (c->dim == 3) {
         if (uni)
-            k_fuse<3, true><<<c->nblk, MD_BLOCK, 0, c->stream>>>(n, s, c->rec[0].p, (size_t)c->ncap, h2);
+            k_fuse<3, true><<<c->nblk, MD_BLOCK, 0, c->stream>>>(n, s, c->rec[0].p, rec_stride(c), h2);
         else
-            k_fuse<3, false><<<c->nblk, MD_BLOCK, 0, c->stream>>>(n, s, c->rec[0].p, (size_t)c->ncap, h2);
+            k_fuse<3, false><<<c->nblk, MD_BLOCK, 0, c->stream>>>(n, s, c->rec[0].p, rec_stride(c), h2);
     } else {
         if (uni)
-            k_fuse<2, true><<<c->nblk, MD_BLOCK, 0, c->stream>>>(n, s, c->rec[0].p, (size_t)c->ncap, h2);
+            k_fuse<2, true><<<c->nblk, MD_BLOCK, 0, c->stream>>>(n, s, c->rec[0].p, rec_stride(c), h2);
         else
-            k_fuse<2, false><<<c->nblk, MD_BLOCK, 0, c->stream>>>(n, s, c->rec[0].p, (size_t)c->ncap, h2);
+            k_fuse<2, false><<<c->nblk, MD_BLOCK, 0, c->stream>>>(n, s, c->rec[0].p, rec_stride(c), h2);
     }
     c->fz_a = 0;
 }
@@ -977,14 +982,14 @@ void fused_leave(md_ctx *c, bool apply_scale)
     int ap = apply_scale ? 1 : 0;
     if (c->dim == 3) {
         if (uni)
-            k_unfuse<3, true><<<c->nblk, MD_BLOCK, 0, c->stream>>>(n, s, rec, (size_t)c->ncap, c->scal.p, ap);
+            k_unfuse<3, true><<<c->nblk, MD_BLOCK, 0, c->stream>>>(n, s, rec, rec_stride(c), c->scal.p, ap);
         else
-            k_unfuse<3, false><<<c->nblk, MD_BLOCK, 0, c->stream>>>(n, s, rec, (size_t)c->ncap, c->scal.p, ap);
+            k_unfuse<3, false><<<c->nblk, MD_BLOCK, 0, c->stream>>>(n, s, rec, rec_stride(c), c->scal.p, ap);
     } else {
         if (uni)
-            k_unfuse<2, true><<<c->nblk, MD_BLOCK, 0, c->stream>>>(n, s, rec, (size_t)c->ncap, c->scal.p, ap);
+            k_unfuse<2, true><<<c->nblk, MD_BLOCK, 0, c->stream>>>(n, s, rec, rec_stride(c), c->scal.p, ap);
         else
-            k_unfuse<2, false><<<c->nblk, MD_BLOCK, 0, c->stream>>>(n, s, rec, (size_t)c->ncap, c->scal.p, ap);
+            k_unfuse<2, false><<<c->nblk, MD_BLOCK, 0, c->stream>>>(n, s, rec, rec_stride(c), c->scal.p, ap);
     }
     c->fz_a = 0;
 }
@@ -1033,7 +1038,7 @@ void launch_step_tpu(md_ctx *c, bool want_uw, double dt, int step)
     StepBufs sbufs{};
     sbufs.recA = c->rec[a].p;
     sbufs.recB = c->rec[a ^ 1].p;
-    sbufs.rstride = (size_t)c->ncap;
+    sbufs.rstride = rec_stride(c);
     for (int d = 0; d < 3; ++d) {
         sbufs.fA[d] = A.f[d].p;
         sbufs.fB[d] = B.f[d].p;
@@ -2718,6 +2723,154 @@ int md_dom_invalidate_inner(md_ctx *ctx)
     API_END
 }
 
+// The fused form of md_dom_run_window (md_domain.hpp, "Fused slab step"): records in, nsteps x (k_step_tile, k_dom_post,
+// all-reduce, record exchange, k_dom_adopt), records out.  The state is canonical (pos / v / f arrays) before and
+// after the call, so list builds, downloads and the caller's planner see what they always saw; after a violation at
+// step m the state returned is that of the last complete step, m - 1, and the caller resumes AT step m (info[6] = 1).
+static bool dom_fused_available(md_ctx *c)
+{
+    return c->dom.on && c->dom.comm && c->allow_fused && c->use_tiles && c->virtual_ghosts && c->pot_kind != POT_CUSTOM &&
+           c->skin > 0.0;
+}
+
+static void dom_exchange_records(md_ctx *ctx, double **sb, double **rb)
+{
+    auto &d = ctx->dom;
+    hipStream_t st = ctx->stream;
+    const int left = (d.rank + d.nranks - 1) % d.nranks, right = (d.rank + 1) % d.nranks;
+    // (order: see md_dom_run_window -- with one or two ranks both neighbours are the same peer)
+    g_rccl.check(g_rccl.GroupStart(), "ncclGroupStart");
+    if (d.nsend_halo[0] > 0) g_rccl.check(g_rccl.Send(sb[0], 6 * d.nsend_halo[0], ncclFloat64, left, d.comm, st), "ncclSend");
+    if (d.nsend_halo[1] > 0) g_rccl.check(g_rccl.Send(sb[1], 6 * d.nsend_halo[1], ncclFloat64, right, d.comm, st), "ncclSend");
+    if (d.nrecv_halo[1] > 0) g_rccl.check(g_rccl.Recv(rb[1], 6 * d.nrecv_halo[1], ncclFloat64, right, d.comm, st), "ncclRecv");
+    if (d.nrecv_halo[0] > 0) g_rccl.check(g_rccl.Recv(rb[0], 6 * d.nrecv_halo[0], ncclFloat64, left, d.comm, st), "ncclRecv");
+    g_rccl.check(g_rccl.GroupEnd(), "ncclGroupEnd");
+}
+
+static int dom_run_window_fused(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, double tau, double nf,
+                                const double *ktemp, const double *r1, const double *r2, int report_last,
+                                int apply_pending_scale, int64_t prune_interval, int32_t *first_viol, double *uwk,
+                                double *info)
+{
+    auto &d = ctx->dom;
+    int rc = md_dom_async_begin(ctx, nsteps, dt, ensemble, tau, nf, ktemp, r1, r2, prune_interval, d.own_flag.p,
+                                d.own_kuw.p);
+    if (rc != 0) return rc;
+    hipStream_t st = ctx->stream;
+    const bool nvt = d.a_nvt;
+    const int n0s = (int)d.nsend_halo[0], n1s = (int)d.nsend_halo[1];
+    const int n0r = (int)d.nrecv_halo[0], n1r = (int)d.nrecv_halo[1];
+    const double shift_l = (d.rank == 0) ? ctx->L[0] : 0.0;
+    const double shift_r = (d.rank == d.nranks - 1) ? -ctx->L[0] : 0.0;
+    double *sb[2], *rb[2];
+    for (int sd = 0; sd < 2; ++sd) {
+        sb[sd] = (d.ext_cap >= 6 * d.nsend_halo[sd]) ? d.ext_send[sd] : d.sbuf[sd].p;
+        rb[sd] = (d.ext_cap >= 6 * d.nrecv_halo[sd]) ? d.ext_recv[sd] : d.rbuf[sd].p;
+    }
+    const int planes = fused_uniform(ctx) ? 3 : 4;
+    const size_t rs = rec_stride(ctx);
+    const int post_grid = 1 + nblocks(std::max(n0s + n1s, 1));
+    const int adopt_grid = nblocks(std::max(n0r + n1r, 1));
+    auto post = [&](int t, int want, const double2 *rec) {
+        k_dom_post<<<post_grid, MD_BLOCK, 0, st>>>(ctx->n > 0 ? ctx->nblk : 0, ctx->partials.p, want, d.kuw_dev, ctx->scal.p, t,
+                                                   n0s, n1s, d.send_slot[0].p, d.send_slot[1].p, rec, rs, shift_l, shift_r,
+                                                   sb[0], sb[1]);
+    };
+    auto adopt = [&](int t, int want, double2 *rec, int finalize) {
+        k_dom_adopt<<<adopt_grid, MD_BLOCK, 0, st>>>(n0r, n1r, d.xh_slot.p, rb[0], rb[1], rec, rs, planes,
+                                                     ctx->sb[ctx->cur].pos.p, d.kuw_dev, want, nvt ? 1 : 0, d.a_nf, d.a_term1,
+                                                     ctx->d_kt.p, ctx->d_r1.p, ctx->d_r2.p, ctx->scal.p, t, finalize);
+    };
+    // records of the state the window starts from: own particles from the arrays, the x-halo particles' from their owners
+    fused_enter(ctx, dt);
+    post(-1, 0, ctx->rec[0].p); // (step -1 < every first_viol: packs; its sums are not used)
+    dom_exchange_records(ctx, sb, rb);
+    adopt(-1, 0, ctx->rec[0].p, 0);
+    // MDHIP_DEBUG_DOM=1: wait after every stage and say so (finds the stage a rank is stuck in)
+    const bool trace = getenv("MDHIP_DEBUG_DOM") != nullptr;
+    int64_t t_now = 0;
+    auto stage = [&](const char *what) {
+        if (!trace) return;
+        HIPCHK(hipStreamSynchronize(st));
+        fprintf(stderr, "[mdhip] rank %d window step %lld: %s done\n", d.rank, (long long)t_now, what);
+    };
+    for (int64_t t = 0; t < nsteps; ++t) {
+        t_now = t;
+        const int want = (report_last && t == nsteps - 1) ? 1 : 0;
+        // inner rows: the schedule (identical on every rank) is the caller's prune interval
+        if (ctx->prune_on && ctx->inner_valid && d.w_prune_interval > 0 && ctx->steps_since_prune >= d.w_prune_interval)
+            ctx->inner_valid = false;
+        if (ctx->prune_on && !ctx->inner_valid) d.w_prune_steps.push_back((int)t);
+        if (ctx->n > 0) {
+            launch_step(ctx, want != 0, dt, (int)t);
+        } else {
+            ctx->fz_a ^= 1;
+            if (ctx->prune_on && !ctx->inner_valid) {
+                ctx->inner_valid = true;
+                ctx->steps_since_prune = 0;
+            }
+        }
+        double2 *recB = ctx->rec[ctx->fz_a].p; // the set this step wrote
+        stage("step");
+        post((int)t, want, recB);
+        g_rccl.check(g_rccl.AllReduce(d.kuw_dev, d.kuw_dev, 4, ncclFloat64, ncclSum, d.comm, st), "ncclAllReduce(K,U,W,viol)");
+        stage("post + all-reduce");
+        dom_exchange_records(ctx, sb, rb);
+        adopt((int)t, want, recB, 1);
+        stage("exchange + adopt");
+        ctx->st_steps += 1;
+        ctx->steps_since_prune += 1;
+    }
+    HIPCHK(hipGetLastError());
+    Scalars h = read_scalars(ctx);
+    const int64_t fv = h.first_viol;
+    const bool violated = fv < nsteps;
+    if (violated) {
+        // steps [0, fv) are complete; step fv read the buffer set that holds the state of step fv - 1: fall back to it
+        const int a_start = (int)((ctx->fz_a ^ (int)(nsteps & 1)) & 1);
+        ctx->fz_a = a_start ^ (int)(fv & 1);
+        ctx->st_steps -= (nsteps - fv);
+    }
+    const bool swapped = ctx->fz_a != 0;
+    fused_leave(ctx, nvt && apply_pending_scale && !violated);
+    if (swapped && n0r + n1r > 0)
+        k_dom_copy_xhalo<<<nblocks(n0r + n1r), MD_BLOCK, 0, st>>>(n0r + n1r, d.xh_slot.p, ctx->sb[ctx->cur ^ 1].pos.p,
+                                                                 ctx->sb[ctx->cur].pos.p);
+    if (nvt && apply_pending_scale && !violated) k_set_scale<<<1, 1, 0, st>>>(ctx->scal.p, 1.0);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));
+    if (first_viol) *first_viol = h.first_viol;
+    if (uwk) {
+        uwk[0] = h.U;
+        uwk[1] = h.W;
+        uwk[2] = h.K;
+    }
+    const int64_t done = violated ? fv : nsteps;
+    if (getenv("MDHIP_DEBUG"))
+        fprintf(stderr, "[mdhip] rank %d fused window: %lld steps, first_viol=%lld, since build %lld, prunes in window %zu\n", d.rank,
+                (long long)nsteps, (long long)fv, (long long)d.w_b0, d.w_prune_steps.size());
+    ctx->steps_since_build = d.w_b0 + done;
+    bool was_prune = false;
+    int last_prune = -1;
+    for (int p : d.w_prune_steps) {
+        if (p == fv) was_prune = true;
+        if (p < fv && p < nsteps) last_prune = p;
+    }
+    if (info) {
+        double d12;
+        unsigned long long bits = h.d1max2_bits;
+        memcpy(&d12, &bits, sizeof d12);
+        info[0] = was_prune ? 1.0 : 0.0;
+        info[1] = std::sqrt(d12);
+        info[2] = last_prune >= 0 ? (double)(d.w_b0 + last_prune + 1) : -1.0;
+        info[3] = ctx->prune_on ? 1.0 : 0.0;
+        info[4] = ctx->skin;
+        info[5] = ctx->prune_on ? ctx->inner_skin : 0.0;
+        info[6] = 1.0; // fused window: after a violation nothing of step first_viol is applied -- resume AT it
+    }
+    return 0;
+}
+
 int md_dom_run_window(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, double tau, double nf, const double *ktemp,
                       const double *r1, const double *r2, int report_last, int apply_pending_scale,
                       int64_t prune_interval, int32_t *first_viol, double *uwk, double *info)
@@ -2739,6 +2892,29 @@ int md_dom_run_window(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, doub
             }
         }
     } guard{ctx};
+    if (info) info[6] = 0.0;
+    {
+        // the fused and the classic window exchange different things: every rank takes the fused one or none does
+        // (a rank whose tiles did not fit the LDS at the last list build walks the generic rows)
+        int32_t hf = dom_fused_available(ctx) ? 1 : 0;
+        hipStream_t st = ctx->stream;
+        HIPCHK(hipMemcpyAsync(d.own_flag.p, &hf, sizeof hf, hipMemcpyHostToDevice, st));
+        g_rccl.check(g_rccl.AllReduce(d.own_flag.p, d.own_flag.p, 1, ncclInt32, ncclMin, d.comm, st), "ncclAllReduce(path)");
+        HIPCHK(hipMemcpyAsync(&hf, d.own_flag.p, sizeof hf, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        ctx->last_run_fused = hf == 1;
+    }
+    if (getenv("MDHIP_DEBUG"))
+        fprintf(stderr, "[mdhip] rank %d md_dom_run_window: %lld steps fused=%d (tiles=%d virtual_ghosts=%d allow=%d) since build %lld inner_valid=%d\n",
+                d.rank, (long long)nsteps, (int)ctx->last_run_fused, (int)ctx->use_tiles, (int)ctx->virtual_ghosts, (int)ctx->allow_fused,
+                (long long)ctx->steps_since_build, (int)ctx->inner_valid);
+    if (ctx->last_run_fused) {
+        if (d.own_kuw.n < 4) throw HipError("md_dom_run_window: internal: K/U/W buffer too small");
+        int rcf = dom_run_window_fused(ctx, nsteps, dt, ensemble, tau, nf, ktemp, r1, r2, report_last, apply_pending_scale,
+                                       prune_interval, first_viol, uwk, info);
+        if (rcf == 0) guard.armed = false;
+        return rcf;
+    }
     int rc = md_dom_async_begin(ctx, nsteps, dt, ensemble, tau, nf, ktemp, r1, r2, prune_interval, d.own_flag.p,
                                 d.own_kuw.p);
     if (rc != 0) return rc;
@@ -2749,7 +2925,10 @@ int md_dom_run_window(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, doub
         int want = (report_last && t == nsteps - 1) ? 1 : 0;
         rc = md_dom_step_a(ctx, dt, (int)t);
         if (rc != 0) return rc;
-        g_rccl.check(g_rccl.AllReduce(d.flag_dev, d.flag_dev, 1, ncclInt32, ncclMin, d.comm, st), "ncclAllReduce(flag)");
+        // (the flag's all-reduce shares one group -- one launch -- with the halo exchange)
+        const bool grouped = g_dom_group_flag;
+        if (!grouped)
+            g_rccl.check(g_rccl.AllReduce(d.flag_dev, d.flag_dev, 1, ncclInt32, ncclMin, d.comm, st), "ncclAllReduce(flag)");
         // halo coordinates to the two ring neighbours.  With one or two ranks both neighbours are the same
         // peer: messages between a pair match in issue order, and a rank's left-bound message is what its
         // peer receives "from the right" -- hence receive-from-right is posted first.
@@ -2759,6 +2938,8 @@ int md_dom_run_window(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, doub
             rb[sd] = (d.ext_cap >= 3 * d.nrecv_halo[sd]) ? d.ext_recv[sd] : d.rbuf[sd].p;
         }
         g_rccl.check(g_rccl.GroupStart(), "ncclGroupStart");
+        if (grouped)
+            g_rccl.check(g_rccl.AllReduce(d.flag_dev, d.flag_dev, 1, ncclInt32, ncclMin, d.comm, st), "ncclAllReduce(flag)");
         if (d.nsend_halo[0] > 0) g_rccl.check(g_rccl.Send(sb[0], 3 * d.nsend_halo[0], ncclFloat64, left, d.comm, st), "ncclSend");
         if (d.nsend_halo[1] > 0) g_rccl.check(g_rccl.Send(sb[1], 3 * d.nsend_halo[1], ncclFloat64, right, d.comm, st), "ncclSend");
         if (d.nrecv_halo[1] > 0) g_rccl.check(g_rccl.Recv(rb[1], 3 * d.nrecv_halo[1], ncclFloat64, right, d.comm, st), "ncclRecv");

@@ -534,7 +534,7 @@ class DomainDevice:
             r1 = np.ascontiguousarray(r1, dtype=np.float64)
             r2 = np.ascontiguousarray(r2, dtype=np.float64)
         uwk = (C.c_double * 3)()
-        info = (C.c_double * 6)()
+        info = (C.c_double * 8)()
         fv = C.c_int32()
         U = W = K = float("nan")
         L, h = self._L, self._h
@@ -558,6 +558,8 @@ class DomainDevice:
             arrs = [a[s:s + wlen].ctypes.data_as(dp) if nvt else None for a in (ktemp, r1, r2)]
             ends_run = s + wlen == nsteps
             window(wlen, dt, ensemble, tau, nf, arrs, nvt, ends_run, Lp, fv, uwk, info)
+            self.windows = getattr(self, "windows", 0) + 1
+            self.fused_windows = getattr(self, "fused_windows", 0) + (1 if info[6] > 0.0 else 0)
             pruning = info[3] > 0.0
             self._skins = (info[4], info[5])
             if fv.value < wlen:
@@ -567,12 +569,15 @@ class DomainDevice:
                 g = s + m
                 last = g == nsteps - 1
                 self.violations += 1
-                ssb = self.steps_since_build + m + 1
+                # fused window (info[6] = 1): steps before m are complete and nothing of step m is applied -- refresh
+                # the rows and resume AT step m.  Classic window: step m's drift is applied, its force half follows here.
+                fused = info[6] > 0.0
+                ssb = self.steps_since_build + m + (0 if fused else 1)
                 rebuild = True
                 if pruning:
                     self._safety = max(0.5, self._safety - 0.02)
                     d0 = self._global_max_disp0()
-                    sample = d0 / ssb
+                    sample = d0 / max(ssb, 1)
                     if not self._rate_known:
                         self._rate, self._rate_known = sample, True
                     elif sample > self._rate:
@@ -586,6 +591,10 @@ class DomainDevice:
                 else:
                     self._chk(L.md_dom_invalidate_inner(h))
                     self.steps_since_build = ssb
+                if fused:
+                    s = g
+                    self._pruning = pruning
+                    continue
                 self._chk(L.md_dom_forces(h, float(dt), 1, 1 if last else 0, uwk))
                 if nvt or last:
                     U, W, K = self.ex.allreduce([uwk[0], uwk[1], uwk[2]])

@@ -11,6 +11,9 @@ sys.path.insert(0, ROOT)
 
 
 def main():
+    # a rank stuck in a collective (its peer failed, or the ranks disagree about what comes next) says where, and ends
+    import faulthandler
+    faulthandler.dump_traceback_later(float(os.environ.get("DOM_WATCHDOG", "240")), exit=True)
     import torch.distributed as dist
     from moleculardynamics.jl_amd import MDDevice, _lib
     from moleculardynamics.jl_amd.domain import DomainDevice, Exchanger
@@ -63,7 +66,7 @@ def main():
         runner = {"0": d.run, "1": d.run_async, "native": d.run_native}[os.environ.get("DOM_ASYNC", "0")]
         Ue, We, Ke = runner(nsteps, dt, ens, 0.1, nf, kt, r1, r2)
         X, V, F, IM = d.gather_global()
-        stats = (d.builds, d.violations, d.counts(), d.stats()["prunes"])
+        stats = (d.builds, d.violations, d.counts(), d.stats()["prunes"], (getattr(d, "fused_windows", 0), getattr(d, "windows", 0)))
     ok = True
     if rank == 0:
         from oracle import oracle as orc
@@ -80,12 +83,16 @@ def main():
             x1, v1, f1, im1 = g.download()
         dx, dv = np.abs(X - x1).max(), np.abs(V - v1).max()
         print(f"[dom] {nsteps} steps {'NVT' if nvt else 'NVE'}: dx={dx:.2e} dv={dv:.2e} dK={abs(Ke-K1)/K1:.2e} "
-              f"dU={abs(Ue-U1)/abs(U1):.2e} images_equal={np.array_equal(IM, im1)} builds={stats[0]} viol={stats[1]} {stats[2]} prunes={stats[3]}")
+              f"dU={abs(Ue-U1)/abs(U1):.2e} images_equal={np.array_equal(IM, im1)} builds={stats[0]} viol={stats[1]} {stats[2]} prunes={stats[3]} fused={stats[4]}")
         ok &= dx <= 1e-8 and dv <= 1e-8 and abs(Ke - K1) <= 1e-9 * K1 and abs(Ue - U1) <= 1e-9 * abs(U1)
         ok &= np.array_equal(IM, im1)
         ok &= stats[0] >= 2          # at least one rebuild with migration happened
         if os.environ.get("DOM_PRUNE", "0") == "1":
             ok &= stats[3] >= 3      # and the inner rows were in use
+        if os.environ.get("DOM_ASYNC", "0") == "native" and os.environ.get("MDHIP_NO_FUSED_STEP", "0") != "1":
+            # md_dom_run_window took the fused step: in every window, unless some rank's tiles stopped fitting the LDS
+            # at a list build (per-particle diameters: 32-byte records) and all ranks went on with the classic sequence
+            ok &= stats[4][0] >= 1 and (stats[4][0] == stats[4][1] or os.environ.get("DOM_POLY", "0") == "1")
     flag = [ok]
     dist.broadcast_object_list(flag, src=0)
     dist.destroy_process_group()

@@ -2,6 +2,7 @@
 with host staging; on a multi-GPU node the same code runs over RCCL).  The decomposed run must
 reproduce the single-handle run and the oracle."""
 import os
+import signal
 import subprocess
 import sys
 
@@ -29,10 +30,19 @@ def _launch(nproc, env_extra, port):
     env["OMP_NUM_THREADS"] = "2"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "domain_gpu_worker.py")]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
-    sys.stdout.write(r.stdout[-3000:])
-    sys.stderr.write(r.stderr[-3000:])
-    assert r.returncode == 0, "slab-decomposed run disagrees with the single-handle run"
+    # own process group: a rank stuck in a collective is ended with its peers when the launcher times out
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        out, err = p.communicate(timeout=float(os.environ.get("DOM_TEST_TIMEOUT", "300")))
+    except subprocess.TimeoutExpired:
+        os.killpg(p.pid, signal.SIGKILL)
+        out, err = p.communicate()
+        sys.stdout.write(out[-3000:])
+        sys.stderr.write(err[-3000:])
+        raise
+    sys.stdout.write(out[-3000:])
+    sys.stderr.write(err[-3000:])
+    assert p.returncode == 0, "slab-decomposed run disagrees with the single-handle run"
 
 
 @pytest.mark.parametrize("nproc,nvt,stage,mode", [
@@ -59,6 +69,10 @@ def _launch(nproc, env_extra, port):
     # BASELINE configs[3]'s geometry (a cube cut into slabs, as bench.py --config 4 does) at 27000 particles: slabs
     # of 10.4 (3 ranks: 3 cells wide) -- and the native loop on it
     (3, 0, "device", "async-prune-cfg4"), (2, 0, "device", "shim-native-prune-cfg4"),
+    # md_dom_run_window takes the fused step on these handles (the worker checks md_get_stats.fused); per-particle
+    # diameters exercise the 4-plane records, and the classic window sequence stays covered with the switch off
+    (2, 1, "device", "shim-native-prune-poly"), (3, 0, "device", "shim-native-poly"),
+    (2, 1, "device", "shim-native-prune-classic"), (1, 1, "", "nccl-native-prune-classic"),
 ])
 def test_slab_decomposition_matches_single_gpu(nproc, nvt, stage, mode):
     # N=8000 -> L=20.7: 2 slabs of 10.4, 3 slabs of 6.9 (>= 2 cells each); kT=2 and dt=0.002 make
@@ -68,6 +82,7 @@ def test_slab_decomposition_matches_single_gpu(nproc, nvt, stage, mode):
            "DOM_ASYNC": "native" if "native" in mode else ("1" if "async" in mode else "0"),
            "MDHIP_RCCL_PATH": _build_shim() if mode.startswith("shim") else "",
            "DOM_PRUNE": "1" if "prune" in mode else "0", "DOM_STEPS": "120" if "prune" in mode else "60",
+           "MDHIP_NO_FUSED_STEP": "1" if mode.endswith("classic") else "0",
            "DOM_POLY": "1" if mode.endswith("poly") else "0", "DOM_ELONG": "1" if mode.endswith("elong") else "0",
            "DOM_N": "8232" if mode.endswith("elong") else ("27000" if mode.endswith("cfg4") else "8000"),   # 8232 = 2 * 4116 = 3 * 2744
            "DOM_BACKEND": "nccl" if mode.startswith("nccl") else "gloo"}
@@ -75,7 +90,9 @@ def test_slab_decomposition_matches_single_gpu(nproc, nvt, stage, mode):
                                                                 "nccl-native": 160, "nccl-native-prune": 200, "async-prune": 240, "async-prune-poly": 280,
                                                                 "sync-poly": 320, "async-prune-elong": 360, "async-elong": 400,
                                                                 "shim-native": 440, "shim-native-prune": 480, "async-prune-cfg4": 520,
-                                                                "shim-native-prune-cfg4": 560}[mode]
+                                                                "shim-native-prune-cfg4": 560, "shim-native-prune-poly": 600,
+                                                                "shim-native-poly": 640, "shim-native-prune-classic": 680,
+                                                                "nccl-native-prune-classic": 720}[mode]
     _launch(nproc, env, port)
 
 
