@@ -237,6 +237,11 @@ int md_dom_async_end(md_ctx *ctx, int apply_pending_scale, int32_t *first_viol, 
  * report_last asks for the global U, W of the window's last step.  List builds stay with the caller.        */
 int md_dom_comm_unique_id(const char *rccl_path, void *id128);
 int md_dom_comm_init(md_ctx *ctx, const char *rccl_path, const void *id128);
+/* The whole list-build sequence above (md_dom_migrate_pack ... md_dom_build) in ONE call, the neighbour exchanges (counts,
+ * migrants, halo records) on the handle's own communicator: no host code between the phases.  Collective; needs
+ * md_dom_comm_init.  With inner rows requested, a rank whose build fell back to the generic rows switches them off on every
+ * rank and the build is repeated (md_dom_counts()[7] tells). */
+int md_dom_rebuild(md_ctx *ctx);
 int md_dom_run_window(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, double tau, double nf, const double *ktemp,
                       const double *r1, const double *r2, int report_last, int apply_pending_scale,
                       int64_t prune_interval, int32_t *first_viol, double *uwk, double *info /* [7] or NULL */);

@@ -22,7 +22,7 @@ EXPORTS = [
     "md_dom_migrate_unpack", "md_dom_halo_pack", "md_dom_halo_unpack", "md_dom_build", "md_dom_get_sendbuf",
     "md_dom_put_recvbuf", "md_dom_set_step_buffers", "md_dom_step_begin", "md_dom_step_end", "md_dom_forces", "md_dom_set_scale",
     "md_dom_counts", "md_set_stream", "md_dom_async_begin", "md_dom_step_a", "md_dom_step_b", "md_dom_step_c",
-    "md_dom_async_end", "md_dom_comm_unique_id", "md_dom_comm_init", "md_dom_run_window",
+    "md_dom_async_end", "md_dom_comm_unique_id", "md_dom_comm_init", "md_dom_run_window", "md_dom_rebuild",
     "md_dom_enable_pruning", "md_dom_max_disp0", "md_dom_invalidate_inner",
 ]
 
@@ -103,6 +103,7 @@ def load():
     L.md_dom_halo_pack.argtypes = [vp, i64p]
     L.md_dom_halo_unpack.argtypes = [vp, i64p]
     L.md_dom_build.argtypes = [vp]
+    L.md_dom_rebuild.argtypes = [vp]
     L.md_dom_get_sendbuf.argtypes = [vp, C.c_int, C.c_int64, C.c_void_p, C.c_int]
     L.md_dom_put_recvbuf.argtypes = [vp, C.c_int, C.c_int64, C.c_void_p, C.c_int]
     L.md_dom_set_step_buffers.argtypes = [vp, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]

@@ -1386,7 +1386,10 @@ __global__ void __launch_bounds__(MD_TILE)
     MD_SSTAMP(1);
     // stage the halo: index loads, then the record gathers, then drift + periodic shift + LDS writes
     // (ordinary steps stage the inner halo, ~1350 records: batches of 6 keep the kernel within 128 registers)
-    constexpr int NB = (!PRUNE && UNIFORM && !WANT_UW) ? 6 : 8;
+#ifndef MD_STAGE_NB
+#define MD_STAGE_NB ((!PRUNE && UNIFORM && !WANT_UW) ? 6 : 8)
+#endif
+    constexpr int NB = MD_STAGE_NB;
     for (int h0 = 0; h0 <= H; h0 += NB * MD_TILE) {
         uint32_t idx[NB];
 #pragma unroll

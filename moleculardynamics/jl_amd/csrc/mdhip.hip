@@ -116,6 +116,7 @@ struct md_ctx {
         ncclComm_t comm = nullptr;
         bool prune_enabled = false; // inner rows on a slab handle: the caller plans the (globally identical) schedule
         DBuf<int32_t> own_flag;
+        DBuf<int64_t> cnt_dev; // list build: record counts to / from the neighbours
         DBuf<double> own_kuw;
     } dom;
     double L[3] = {1, 1, 1};
@@ -636,7 +637,7 @@ void rebuild_t(md_ctx *c)
         // (uniform: 4 x 40 KB; per-particle diameters: 3 x 53 KB), never more than the outer halo itself
         const size_t target = (c->tile_rs == 24) ? (40 * 1024 - 256) : (53 * 1024);
         int cap_in = (int)std::min<size_t>((size_t)c->hstride, target / c->tile_rs - 1);
-        if (c->dom.on) cap_in = c->hstride; // (a slab handle's prune step must not fail: see launch_force_tpu)
+        if (c->dom.on || getenv("MDHIP_INNER_CAP_OUTER")) cap_in = c->hstride; // (a slab handle's prune step must not fail: see launch_force_tpu)
         c->hcap_in = std::max(cap_in, 1);
         c->tile_lds_in = (((size_t)(c->hcap_in + 1) * c->tile_rs) + 15) & ~(size_t)15;
         c->halo_in.ensure((size_t)c->nblk * c->hcap_in);
@@ -1205,7 +1206,10 @@ static int create_common(int dim, int64_t n_global, int64_t n_cap, bool domain, 
         if (const char *e = getenv("MDHIP_NO_FUSED_BUILD")) ctx->allow_fused_build = !(e[0] == '1');
         if (const char *e = getenv("MDHIP_INNER_SKIN")) ctx->inner_skin_req = atof(e);
         if (const char *e = getenv("MDHIP_NO_FUSED_STEP")) ctx->allow_fused = !(e[0] == '1');
-        if (const char *e = getenv("MDHIP_NO_INNER_HALO")) ctx->allow_inner_halo = !(e[0] == '1');
+        // inner halo (md_kernels.hpp, tile_inner_halo): off unless asked for -- the box test trims only ~4 % of a
+        // tile's staged set (tiles straddle bricks; measured) and costs the prune step a block of occupancy
+        ctx->allow_inner_halo = false;
+        if (const char *e = getenv("MDHIP_INNER_HALO")) ctx->allow_inner_halo = (e[0] == '1');
         // default potential: LennardJones() -- src/potentials.jl:52-64
         ctx->pot_kind = POT_LJ;
         ctx->pp.p[0] = 1.0;
@@ -1514,6 +1518,7 @@ int md_neighbor_pairs(md_ctx *ctx, int32_t *pairs, int64_t cap, int64_t *count)
     API_END
 }
 
+static void debug_tile_halos(md_ctx *ctx);
 int md_run(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, double tau, double nf, const double *ktemp,
            const double *r1, const double *r2, double *uwk)
 {
@@ -1816,6 +1821,7 @@ int md_run(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, double tau, dou
         k_clear_halo_overflow<<<1, 1, 0, st>>>(ctx->scal.p);
         HIPCHK(hipStreamSynchronize(st));
     }
+    debug_tile_halos(ctx);
     ctx->st_steps += nsteps;
     API_END
 }
@@ -2723,6 +2729,83 @@ int md_dom_invalidate_inner(md_ctx *ctx)
     API_END
 }
 
+// A failure on this rank between collectives would leave its peers blocked inside theirs: abort the communicator
+// first so that they fail fast instead of hanging (the handle needs md_dom_comm_init again).
+struct DomAbortGuard {
+    md_ctx *c;
+    bool armed = true;
+    ~DomAbortGuard()
+    {
+        if (armed && c->dom.comm && g_rccl.CommAbort) {
+            (void)g_rccl.CommAbort(c->dom.comm);
+            c->dom.comm = nullptr;
+        }
+    }
+};
+
+// Neighbour exchange of record sets whose sizes only the sender knows (migrants, halo records of a list build): the
+// counts travel first, then the payloads straight from / into the library's exchange buffers, on the handle's stream.
+// (issue order: see md_dom_run_window -- with one or two ranks both neighbours are the same peer)
+static void dom_exchange_var(md_ctx *ctx, const int64_t *nsend, int rec, int64_t *nrecv)
+{
+    auto &d = ctx->dom;
+    hipStream_t st = ctx->stream;
+    const int left = (d.rank + d.nranks - 1) % d.nranks, right = (d.rank + 1) % d.nranks;
+    d.cnt_dev.ensure(4);
+    int64_t hc[4] = {nsend[0], nsend[1], 0, 0};
+    HIPCHK(hipMemcpyAsync(d.cnt_dev.p, hc, 2 * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    g_rccl.check(g_rccl.GroupStart(), "ncclGroupStart");
+    g_rccl.check(g_rccl.Send(d.cnt_dev.p + 0, 1, ncclInt64, left, d.comm, st), "ncclSend(count)");
+    g_rccl.check(g_rccl.Send(d.cnt_dev.p + 1, 1, ncclInt64, right, d.comm, st), "ncclSend(count)");
+    g_rccl.check(g_rccl.Recv(d.cnt_dev.p + 3, 1, ncclInt64, right, d.comm, st), "ncclRecv(count)");
+    g_rccl.check(g_rccl.Recv(d.cnt_dev.p + 2, 1, ncclInt64, left, d.comm, st), "ncclRecv(count)");
+    g_rccl.check(g_rccl.GroupEnd(), "ncclGroupEnd");
+    HIPCHK(hipMemcpyAsync(hc + 2, d.cnt_dev.p + 2, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    nrecv[0] = hc[2]; // from the left neighbour
+    nrecv[1] = hc[3]; // from the right neighbour
+    for (int sd = 0; sd < 2; ++sd) {
+        if (nrecv[sd] < 0 || (size_t)(nrecv[sd] * rec) > d.rbuf[sd].n)
+            throw HipError("list build: a neighbour sends more records than the exchange buffers hold (raise n_cap)");
+        if ((size_t)(nsend[sd] * rec) > d.sbuf[sd].n) throw HipError("list build: send buffer exceeded (raise n_cap)");
+    }
+    if (nsend[0] + nsend[1] + nrecv[0] + nrecv[1] == 0) return;
+    g_rccl.check(g_rccl.GroupStart(), "ncclGroupStart");
+    if (nsend[0] > 0) g_rccl.check(g_rccl.Send(d.sbuf[0].p, nsend[0] * rec, ncclFloat64, left, d.comm, st), "ncclSend");
+    if (nsend[1] > 0) g_rccl.check(g_rccl.Send(d.sbuf[1].p, nsend[1] * rec, ncclFloat64, right, d.comm, st), "ncclSend");
+    if (nrecv[1] > 0) g_rccl.check(g_rccl.Recv(d.rbuf[1].p, nrecv[1] * rec, ncclFloat64, right, d.comm, st), "ncclRecv");
+    if (nrecv[0] > 0) g_rccl.check(g_rccl.Recv(d.rbuf[0].p, nrecv[0] * rec, ncclFloat64, left, d.comm, st), "ncclRecv");
+    g_rccl.check(g_rccl.GroupEnd(), "ncclGroupEnd");
+}
+
+// MDHIP_DEBUG=1: the sizes of the tiles' halos (outer: staged by prune steps; inner: staged by ordinary steps)
+static void debug_tile_halos(md_ctx *ctx)
+{
+    if (!getenv("MDHIP_DEBUG") || ctx->nblk <= 0 || !ctx->use_tiles) return;
+    if (!ctx->inner_halo_live || ctx->halo_in_count.n < (size_t)ctx->nblk) {
+        fprintf(stderr, "[mdhip] tile halos: no inner halo in use (allowed %d, inner rows %d valid %d)\n", (int)ctx->allow_inner_halo,
+                (int)ctx->prune_on, (int)ctx->inner_valid);
+        return;
+    }
+    std::vector<int32_t> hi(ctx->nblk), ho(ctx->nblk);
+    HIPCHK(hipMemcpy(hi.data(), ctx->halo_in_count.p, ctx->nblk * sizeof(int32_t), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(ho.data(), ctx->halo_count.p, ctx->nblk * sizeof(int32_t), hipMemcpyDeviceToHost));
+    long long si = 0, so = 0;
+    int mi = 0, mo = 0, argmax = 0;
+    for (int b = 0; b < ctx->nblk; ++b) {
+        si += hi[b];
+        so += ho[b];
+        if (hi[b] > mi) {
+            mi = hi[b];
+            argmax = b;
+        }
+        mo = std::max(mo, ho[b]);
+    }
+    fprintf(stderr, "[mdhip] tile halos: outer mean %.0f max %d; inner mean %.0f max %d (tile %d of %d); cap %d; rc %.3f skin %.3f inner skin %.3f\n",
+            (double)so / ctx->nblk, mo, (double)si / ctx->nblk, mi, argmax, ctx->nblk, ctx->hcap_in, ctx->rc, ctx->skin,
+            ctx->inner_skin);
+}
+
 // The fused form of md_dom_run_window (md_domain.hpp, "Fused slab step"): records in, nsteps x (k_step_tile, k_dom_post,
 // all-reduce, record exchange, k_dom_adopt), records out.  The state is canonical (pos / v / f arrays) before and
 // after the call, so list builds, downloads and the caller's planner see what they always saw; after a violation at
@@ -2846,6 +2929,7 @@ static int dom_run_window_fused(md_ctx *ctx, int64_t nsteps, double dt, int ense
         uwk[2] = h.K;
     }
     const int64_t done = violated ? fv : nsteps;
+    debug_tile_halos(ctx);
     if (getenv("MDHIP_DEBUG"))
         fprintf(stderr, "[mdhip] rank %d fused window: %lld steps, first_viol=%lld, since build %lld, prunes in window %zu\n", d.rank,
                 (long long)nsteps, (long long)fv, (long long)d.w_b0, d.w_prune_steps.size());
@@ -2879,19 +2963,7 @@ int md_dom_run_window(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, doub
     dom_require(ctx);
     auto &d = ctx->dom;
     if (!d.comm) throw HipError("md_dom_run_window: no communicator (md_dom_comm_init first)");
-    // A failure on this rank between the per-step collectives would leave its peers blocked inside theirs: abort the
-    // communicator first so that they fail fast instead of hanging (the handle needs md_dom_comm_init again).
-    struct AbortGuard {
-        md_ctx *c;
-        bool armed = true;
-        ~AbortGuard()
-        {
-            if (armed && c->dom.comm && g_rccl.CommAbort) {
-                (void)g_rccl.CommAbort(c->dom.comm);
-                c->dom.comm = nullptr;
-            }
-        }
-    } guard{ctx};
+    DomAbortGuard guard{ctx};
     if (info) info[6] = 0.0;
     {
         // the fused and the classic window exchange different things: every rank takes the fused one or none does
@@ -2970,6 +3042,45 @@ int md_dom_set_scale(md_ctx *ctx, double scale)
     dom_require(ctx);
     k_set_scale<<<1, 1, 0, ctx->stream>>>(ctx->scal.p, scale);
     HIPCHK(hipGetLastError());
+    API_END
+}
+
+// The whole list build of a slab handle in one call, the neighbour exchanges on the handle's own communicator:
+// md_dom_migrate_pack -> counts + migrants -> md_dom_migrate_unpack -> md_dom_halo_pack -> counts + halo records ->
+// md_dom_halo_unpack -> md_dom_build.  Collective.  Inner rows need the tiled kernel on every rank (the prune steps are
+// scheduled once for all ranks): if some rank's build fell back, pruning is switched off everywhere and the build repeated.
+int md_dom_rebuild(md_ctx *ctx)
+{
+    API_BEGIN
+    dom_require(ctx);
+    auto &d = ctx->dom;
+    if (!d.comm) throw HipError("md_dom_rebuild: no communicator (md_dom_comm_init first)");
+    DomAbortGuard guard{ctx};
+    auto sub = [&](int rc) {
+        if (rc != 0) throw HipError(ctx->err);
+    };
+    for (int attempt = 0;; ++attempt) {
+        int64_t ns[2] = {0, 0}, nr[2] = {0, 0};
+        sub(md_dom_migrate_pack(ctx, ns));
+        dom_exchange_var(ctx, ns, MD_MIG_REC, nr);
+        sub(md_dom_migrate_unpack(ctx, nr));
+        sub(md_dom_halo_pack(ctx, ns));
+        dom_exchange_var(ctx, ns, MD_HALO_REC, nr);
+        sub(md_dom_halo_unpack(ctx, nr));
+        sub(md_dom_build(ctx));
+        // (every rank asked for inner rows or none did: prune_enabled is set by the same caller code on all of them)
+        if (!d.prune_enabled || attempt > 0) break;
+        hipStream_t st = ctx->stream;
+        int32_t hf = ctx->prune_on ? 1 : 0;
+        HIPCHK(hipMemcpyAsync(d.own_flag.p, &hf, sizeof hf, hipMemcpyHostToDevice, st));
+        g_rccl.check(g_rccl.AllReduce(d.own_flag.p, d.own_flag.p, 1, ncclInt32, ncclMin, d.comm, st), "ncclAllReduce(inner rows)");
+        HIPCHK(hipMemcpyAsync(&hf, d.own_flag.p, sizeof hf, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (hf == 1) break;
+        d.prune_enabled = false;
+        ctx->list_valid = false;
+    }
+    guard.armed = false;
     API_END
 }
 

@@ -365,6 +365,20 @@ class DomainDevice:
             if tm is not None:
                 tm.append(time.perf_counter())
 
+        if getattr(self, "_native_ready", False):
+            # the library's own communicator is up (run_native): the whole sequence in one call, exchanges on RCCL
+            self._chk(self._L.md_dom_rebuild(self._h)); lap()
+            c = self.counts()
+            self._nsend_halo, self._nrecv_halo = c["nsend_halo"], c["nrecv_halo"]
+            self._bind_step_buffers()
+            self.steps_since_build = 0
+            self.builds += 1
+            if getattr(self, "_prune_req", False) and not c["pruning"]:
+                self._prune_req = False     # some rank's tiles did not fit: nobody prunes (md_dom_rebuild agreed on it)
+                self._pruning = False
+            if tm is not None and self.rank == 0:
+                print(f"[dom build] native total={1e6 * (tm[-1] - tm[0]):.0f}us", flush=True)
+            return
         ns = (C.c_int64 * 2)()
         self._chk(self._L.md_dom_migrate_pack(self._h, ns)); lap()
         nrecv = self._exchange((ns[0], ns[1]), MIG_REC); lap()

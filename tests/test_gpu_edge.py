@@ -264,3 +264,37 @@ def test_wrap_lands_exactly_on_the_box_length(oracle):
             x, v, img0 = ref["x"], ref["v"], ref["img"]
             # (the device continues from ITS state: unwrapped coordinates, same physical points)
     assert tuple(ref["img"][:, 0]) == (-1, 1, 1, 0)
+
+
+def test_inner_halo_switch_changes_nothing_but_the_staging(oracle, monkeypatch):
+    """MDHIP_INNER_HALO=1 (read at md_create): ordinary steps stage only the records the box test of the last prune step
+    kept, through a translated set of row offsets.  Off by default (it trims ~4 % at liquid density, DESIGN.md section 3);
+    the path stays covered here: the trajectory of the default staging, prunes and rebuilds included, and the oracle's
+    within the fused loop's tolerance."""
+    from moleculardynamics.jl_amd import MDDevice, _lib
+    from tests.util import lj_system
+    n, nsteps, dt = 32768, 90, 0.002
+    s = lj_system(n, kT=2.0)
+    rng = np.random.default_rng(3)
+    nf = 3 * (n - 1.0)
+    r1, r2 = rng.standard_normal(nsteps), 2.0 * rng.gamma((nf - 1) / 2, size=nsteps)
+    kt = np.full(nsteps, 2.0)
+    out = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("MDHIP_INNER_HALO", flag)
+        with MDDevice(3, n, s["box"], 2.5) as d:
+            d.set_potential(0, LJ)
+            d.upload(s["x"], s["v"], s["f"], s["img"], s["diam"])
+            uwk = d.run(nsteps, dt, _lib.MD_NVT, 0.1, nf, kt, r1, r2)
+            out[flag] = (d.download(), tuple(uwk), d.stats())
+    (x0, v0, f0, i0), u0, st0 = out["0"]
+    (x1, v1, f1, i1), u1, st1 = out["1"]
+    assert st0["fused"] == 1 and st1["fused"] == 1 and st1["prunes"] >= 3 and st1["rebuilds"] >= 2
+    # (not bit for bit: a tile whose inner halo does not fit costs one extra prune step, after which the inner rows
+    # list their entries in another order)
+    assert np.array_equal(i0, i1) and np.abs(x0 - x1).max() <= 1e-9 and np.abs(v0 - v1).max() <= 1e-9
+    assert np.abs(f0 - f1).max() <= 1e-7 * max(1.0, np.abs(f0).max())
+    assert all(abs(a - b) <= 1e-9 * max(1.0, abs(a)) for a, b in zip(u0, u1))
+    ref = oracle.run(s["x"], s["img"], s["v"], s["f"], s["diam"], s["box"], 2.5, oracle.make_pot(0, LJ), dt, nsteps, ensemble=1,
+                     tau=0.1, ktemp=kt, r1=r1, r2=r2, nthreads=8)
+    assert np.array_equal(i1, ref["img"]) and np.abs(x1 - ref["x"]).max() <= 1e-8
