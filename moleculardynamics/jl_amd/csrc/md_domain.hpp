@@ -352,12 +352,10 @@ __global__ void __launch_bounds__(MD_BLOCK)
         __shared__ double red[16];
         double a = 0.0, b = 0.0, c = 0.0;
         if (!(fv < step)) {
-            for (int i = threadIdx.x; i < nblk; i += blockDim.x) {
-                a += partials[i];
-                if (want_uw) {
-                    b += partials[nblk + i];
-                    c += partials[2 * nblk + i];
-                }
+            a = strided_sum<16>(partials, nblk);
+            if (want_uw) {
+                b = strided_sum<16>(partials + nblk, nblk);
+                c = strided_sum<16>(partials + 2 * nblk, nblk);
             }
         }
         a = block_sum(a, red);

@@ -183,6 +183,26 @@ __device__ __forceinline__ double block_sum(double v, double *lds /* >= 16 doubl
     return r;
 }
 
+// Thread t's share of a fixed-order sum over v[0..n): elements t, t + B, t + 2B, ... added in that order (B = block
+// size).  The loads go out BATCH at a time -- one memory latency per batch instead of one per element.
+template <int BATCH>
+__device__ __forceinline__ double strided_sum(const double *__restrict__ v, int n)
+{
+    const int B = blockDim.x;
+    double a = 0.0;
+    for (int i0 = threadIdx.x; i0 < n; i0 += BATCH * B) {
+        double t[BATCH];
+#pragma unroll
+        for (int q = 0; q < BATCH; ++q) {
+            int i = i0 + q * B;
+            t[q] = (i < n) ? v[i] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < BATCH; ++q) a += t[q];
+    }
+    return a;
+}
+
 // exclusive scan of one int per thread over the block; returns the prefix, *total gets the
 // block sum.  lds: >= 16 ints.  Contains barriers: call from uniform control flow.
 __device__ __forceinline__ int block_excl_scan(int v, int *lds, int *total)
@@ -1668,13 +1688,10 @@ __global__ void __launch_bounds__(1024)
 {
     __shared__ double red[16];
     if (sc->first_viol <= step) return;
-    double a = 0.0, b = 0.0, c = 0.0;
-    for (int i = threadIdx.x; i < nblk; i += blockDim.x) {
-        a += partials[i];
-        if (want_uw) {
-            b += partials[nblk + i];
-            c += partials[2 * nblk + i];
-        }
+    double a = strided_sum<4>(partials, nblk), b = 0.0, c = 0.0;
+    if (want_uw) {
+        b = strided_sum<4>(partials + nblk, nblk);
+        c = strided_sum<4>(partials + 2 * nblk, nblk);
     }
     a = block_sum(a, red);
     if (want_uw) {
