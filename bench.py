@@ -38,9 +38,9 @@ STEP_BYTES = {"nve": 332.0, "nvt": 380.0}   # algorithmi
 KICKDRIFT_BYTES = 160           # classic loop: R pos 32 + v 24 + f 24 + x1 24, W pos 32 + v 24
 FORCE_KERNEL_BYTES = 96.0       # classic loop's force kernel: R pos 32 + v 24, W f 24 + v 24
 # ISA-counted budget of the pair loop (scripts/isa_budget.py on k_step_tile<3, LJ, uniform, no energies>):
-# per 8 candidates 138 full-rate fp64 instructions, 4 v_rcp_f64 (quarter rate: 4 slots each), 63 32-bit VALU
-# (half a slot each) = 185.5 fp64-rate issue slots
-VALU_SLOTS_PER_CANDIDATE = 185.5 / 8.0
+# per 8 candidates 137 full-rate fp64 instructions, 4 v_rcp_f64 (quarter rate: 4 slots each), 46 32-bit VALU
+# (half a slot each) = 176 fp64-rate issue slots
+VALU_SLOTS_PER_CANDIDATE = 176.0 / 8.0
 FP64_SPEC_SLOTS = 256 * 4 * 2.4e9 / 4.0     # datasheet: 1024 SIMDs, one wave64 fp64 instruction per 4 clocks at 2.4 GHz
 KERNEL_SOURCES = ["md_kernels.hpp", "md_build_tile.hpp", "mdhip.hip"]
 
@@ -376,10 +376,14 @@ def main():
         "config": {
             "workload": workload,
             "particles_per_gpu": n_local if scaling == "weak" else total_particles / world,
-            "parallelism": "1 GPU" if not use_domain else f"{world}-way 1-D slab decomposition along x, halo exchange every "
-                                                            f"step over torch.distributed ({dist.get_backend()}), "
-                                                            f"step loop: {loop}",
-            "step_loop": "fused (k_step_tile: one launch per step + k_finalize)" if fused else "classic (k_kickdrift, k_force_tile, k_finalize)",
+            "parallelism": "1 GPU" if not use_domain else (
+                f"{world}-way 1-D slab decomposition along x; step windows and list builds inside the library "
+                f"(md_dom_run_window, md_dom_rebuild), collectives on its own RCCL communicator" if loop == "native" else
+                f"{world}-way 1-D slab decomposition along x, halo exchange every step over torch.distributed "
+                f"({dist.get_backend()}), step loop: {loop}"),
+            "step_loop": ("classic (k_kickdrift, k_force_tile, k_finalize)" if not fused else
+                          "fused (k_step_tile: one launch per step + k_finalize)" if not use_domain else
+                          "fused slab step (k_step_tile, k_dom_post, all-reduce, record exchange, k_dom_adopt)"),
             "skin": a.skin if a.skin is not None else (0.6 if (not use_domain or st1["prunes"] > 0) else 0.4),
             "rebuilds_in_timed_region": st1["rebuilds"] - st0["rebuilds"],
             "global_particles": total_particles,

@@ -345,10 +345,11 @@ __global__ void __launch_bounds__(MD_BLOCK)
     k_dom_post(int nblk, const double *__restrict__ partials, int want_uw, double *__restrict__ kuw4, const Scalars *sc,
                int step, int n0, int n1, const int32_t *__restrict__ slot0, const int32_t *__restrict__ slot1,
                const double2 *__restrict__ rec, size_t rstride, double shift0, double shift1,
-               double *__restrict__ out0, double *__restrict__ out1)
+               double *__restrict__ out0, double *__restrict__ out1, int what /* 1 = sums, 2 = pack, 3 = both */)
 {
     const int fv = sc->first_viol;
     if (blockIdx.x == 0) {
+        if (!(what & 1)) return;
         __shared__ double red[16];
         double a = 0.0, b = 0.0, c = 0.0;
         if (!(fv < step)) {
@@ -369,7 +370,7 @@ __global__ void __launch_bounds__(MD_BLOCK)
         }
         return;
     }
-    if (fv < step) return; // (an earlier step was violated: this one did not run)
+    if (fv < step || !(what & 2)) return; // (an earlier step was violated: this one did not run)
     int j = (blockIdx.x - 1) * blockDim.x + threadIdx.x;
     const int32_t *slot = slot0;
     double *out = out0;
@@ -443,4 +444,26 @@ __global__ void __launch_bounds__(MD_BLOCK)
     if (j >= ntot) return;
     const size_t k = (size_t)xh_slot[j];
     to[k] = from[k];
+}
+
+// Boundary tiles of a slab handle (list build): a tile whose staged set holds an x-halo slot needs the neighbours'
+// records before it can step; a tile that owns a particle of the send lists produces records the neighbours wait for.
+// Every other tile is interior: the fused window steps it while the boundary records travel.
+__global__ void __launch_bounds__(MD_BLOCK)
+    k_dom_tile_class(int nblk, const uint32_t *__restrict__ halo, int hcap, const int32_t *__restrict__ halo_count, int n_own,
+                     int32_t *__restrict__ flag)
+{
+    const int bid = blockIdx.x;
+    if (bid >= nblk) return;
+    const int H = halo_count[bid];
+    const uint32_t *hl = halo + (size_t)bid * hcap;
+    int any = 0;
+    for (int h = threadIdx.x; h < H; h += blockDim.x) any |= ((int)(hl[h] & 0x3ffffffu) >= n_own) ? 1 : 0;
+    if (__any(any) && (threadIdx.x & 63) == 0) flag[bid] = 1;
+}
+
+__global__ void __launch_bounds__(MD_BLOCK) k_dom_mark_send(int n, const int32_t *__restrict__ slot, int32_t *__restrict__ flag)
+{
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) flag[slot[j] / MD_TILE] = 1;
 }

@@ -1359,7 +1359,7 @@ __global__ void __launch_bounds__(MD_TILE)
                 double *__restrict__ partials, int nblk_total, Scalars *__restrict__ sc, int step,
                 uint16_t *__restrict__ rows_in, int32_t *__restrict__ nmax_in, double rin2,
                 long long *__restrict__ stamps, uint32_t *__restrict__ halo_in, int hcap_in,
-                int32_t *__restrict__ halo_in_count)
+                int32_t *__restrict__ halo_in_count, const int32_t *__restrict__ tile_list = nullptr)
 {
 #define MD_SSTAMP(i)                                                                                   \
     do {                                                                                               \
@@ -1373,7 +1373,9 @@ __global__ void __launch_bounds__(MD_TILE)
     // every block writes its x_n, which the host needs to decide between a prune and a rebuild)
     if (sc->first_viol < step) return;
     MD_SSTAMP(0);
+    // (tile_list: a launch over a subset of the tiles -- the slab windows run the boundary tiles ahead of the interior)
     int bid = xcd_remap(blockIdx.x, gridDim.x);
+    if (tile_list) bid = tile_list[bid];
     int H = halo_count[bid];
     const uint32_t *hl = halo + (size_t)bid * hcap;
     int k = bid * MD_TILE + threadIdx.x;

@@ -117,6 +117,11 @@ struct md_ctx {
         bool prune_enabled = false; // inner rows on a slab handle: the caller plans the (globally identical) schedule
         DBuf<int32_t> own_flag;
         DBuf<int64_t> cnt_dev; // list build: record counts to / from the neighbours
+        // fused window: boundary tiles (x-halo in their staged set, or owners of send-list particles) and the rest
+        DBuf<int32_t> tile_flag, tiles_b, tiles_i;
+        int n_tiles_b = 0, n_tiles_i = 0;
+        hipStream_t stream_i = nullptr; // the interior tiles' stream
+        hipEvent_t ev_go = nullptr, ev_int = nullptr;
         DBuf<double> own_kuw;
     } dom;
     double L[3] = {1, 1, 1};
@@ -217,6 +222,13 @@ struct md_ctx {
     int64_t prof_kd_launch_acc = 0;
     int64_t prof_prune_acc = 0;   // timed force/step launches that were prune steps
     bool last_run_fused = false;
+    // launch_step over a subset of the tiles (slab windows: boundary tiles ahead of the interior ones)
+    struct StepPart {
+        const int32_t *list = nullptr;
+        int count = 0;
+        hipStream_t stream = nullptr;
+        bool last = true; // the launch that completes the step: host-side bookkeeping happens here
+    } part;
 
     std::string err;
 
@@ -1010,9 +1022,12 @@ void launch_step_tpu(md_ctx *c, bool want_uw, double dt, int step)
     int use_d1 = use_inner ? 1 : 0;
     DevState s = c->dev(c->cur); // x1 = the prune positions while the inner rows are valid, else x0
     double rin = c->rc + c->inner_skin;
+    const bool whole = c->part.list == nullptr;
+    hipStream_t lst = whole ? c->stream : c->part.stream;
+    const int grid = whole ? nb : c->part.count;
     if (prune_step) {
         for (int d = 0; d < 3; ++d) s.x1[d] = c->x1[d].p; // the prune step writes the new reference positions
-        k_reset_d1<<<1, 1, 0, c->stream>>>(c->scal.p, step - 1);
+        if (whole) k_reset_d1<<<1, 1, 0, c->stream>>>(c->scal.p, step - 1); // (a split step: the caller did, ahead of all parts)
     }
     // which halo image the launch stages: the outer one (prune steps, and whenever there is no inner halo), or the
     // inner one the last prune step left behind
@@ -1054,14 +1069,15 @@ void launch_step_tpu(md_ctx *c, bool want_uw, double dt, int step)
                                        (int)(160 * 1024 - 2048)));                                                  \
             attr_dev_mask |= 1 << (c->device & 31);                                                                 \
         }                                                                                                           \
-        kfn<<<nb, MD_TILE, lds_bytes, c->stream>>>(n, s, sbufs, c->pp, rows16, c->maxn, rowmax, halo_p, halo_cap,   \
+        if (grid > 0)                                                                                               \
+            kfn<<<grid, MD_TILE, lds_bytes, lst>>>(n, s, sbufs, c->pp, rows16, c->maxn, rowmax, halo_p, halo_cap,   \
                                                    halo_cnt, dt, skin_half, inner_half, use_d1,                     \
                                                    c->partials.p, nb, c->scal.p, step, c->nlist16_in.p,             \
                                                    c->nmax_tile_in.p, rin * rin, c->dbg_stamps.p, hin_p,            \
-                                                   c->hcap_in, c->halo_in_count.p);                                 \
+                                                   c->hcap_in, c->halo_in_count.p, c->part.list);                   \
     } while (0)
-    prof_begin(c);
-    if (prune_step && c->prof_open) c->prof_prune_acc++;
+    if (whole) prof_begin(c);
+    if (whole && prune_step && c->prof_open) c->prof_prune_acc++;
     if (prune_step) {
         if (want_uw)
             LS(true, true);
@@ -1073,8 +1089,9 @@ void launch_step_tpu(md_ctx *c, bool want_uw, double dt, int step)
         else
             LS(false, false);
     }
-    prof_end(c);
+    if (whole) prof_end(c);
 #undef LS
+    if (!whole && !c->part.last) return; // (more parts of this step follow)
     c->fz_a ^= 1;
     if (prune_step) {
         c->inner_valid = true;
@@ -1308,6 +1325,12 @@ int md_destroy(md_ctx *ctx)
     }
     delete ctx->rtc;
     ctx->rtc = nullptr;
+    if (ctx->dom.stream_i) {
+        (void)hipStreamSynchronize(ctx->dom.stream_i);
+        (void)hipStreamDestroy(ctx->dom.stream_i);
+        (void)hipEventDestroy(ctx->dom.ev_go);
+        (void)hipEventDestroy(ctx->dom.ev_int);
+    }
     if (ctx->dom.comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(ctx->dom.comm);
     ctx->dom.comm = nullptr;
     for (auto &p : ctx->prof_ev) {
@@ -2352,6 +2375,36 @@ int md_dom_halo_unpack(md_ctx *ctx, const int64_t *nrecv)
     API_END
 }
 
+// after a list build: which tiles touch the slab faces (md_domain.hpp, k_dom_tile_class)
+static void dom_classify_tiles(md_ctx *ctx)
+{
+    auto &d = ctx->dom;
+    d.n_tiles_b = d.n_tiles_i = 0;
+    if (!ctx->use_tiles || !ctx->virtual_ghosts || ctx->n <= 0) return;
+    hipStream_t st = ctx->stream;
+    const int nb = ctx->nblk;
+    d.tile_flag.ensure(nb);
+    d.tiles_b.ensure(nb);
+    d.tiles_i.ensure(nb);
+    HIPCHK(hipMemsetAsync(d.tile_flag.p, 0, nb * sizeof(int32_t), st));
+    k_dom_tile_class<<<nb, MD_BLOCK, 0, st>>>(nb, ctx->halo.p, ctx->hcap, ctx->halo_count.p, (int)ctx->n, d.tile_flag.p);
+    for (int sd = 0; sd < 2; ++sd)
+        if (d.nsend_halo[sd] > 0)
+            k_dom_mark_send<<<nblocks(d.nsend_halo[sd]), MD_BLOCK, 0, st>>>((int)d.nsend_halo[sd], d.send_slot[sd].p, d.tile_flag.p);
+    HIPCHK(hipGetLastError());
+    std::vector<int32_t> fl(nb), lb, li;
+    HIPCHK(hipMemcpyAsync(fl.data(), d.tile_flag.p, nb * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (int b = 0; b < nb; ++b) (fl[b] ? lb : li).push_back(b);
+    if (!lb.empty()) HIPCHK(hipMemcpyAsync(d.tiles_b.p, lb.data(), lb.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    if (!li.empty()) HIPCHK(hipMemcpyAsync(d.tiles_i.p, li.data(), li.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st)); // (the host vectors go out of scope)
+    d.n_tiles_b = (int)lb.size();
+    d.n_tiles_i = (int)li.size();
+    if (getenv("MDHIP_DEBUG"))
+        fprintf(stderr, "[mdhip] rank %d slab tiles: %d boundary, %d interior\n", d.rank, d.n_tiles_b, d.n_tiles_i);
+}
+
 // step 5: sort, ghosts, neighbour rows; fix the per-step halo slot tables
 int md_dom_build(md_ctx *ctx)
 {
@@ -2372,6 +2425,7 @@ int md_dom_build(md_ctx *ctx)
     HIPCHK(hipStreamSynchronize(st));
     d.n_old = ctx->n;
     d.n_arr = 0;
+    dom_classify_tiles(ctx);
     API_END
 }
 
@@ -2854,19 +2908,34 @@ static int dom_run_window_fused(md_ctx *ctx, int64_t nsteps, double dt, int ense
     const size_t rs = rec_stride(ctx);
     const int post_grid = 1 + nblocks(std::max(n0s + n1s, 1));
     const int adopt_grid = nblocks(std::max(n0r + n1r, 1));
-    auto post = [&](int t, int want, const double2 *rec) {
-        k_dom_post<<<post_grid, MD_BLOCK, 0, st>>>(ctx->n > 0 ? ctx->nblk : 0, ctx->partials.p, want, d.kuw_dev, ctx->scal.p, t,
-                                                   n0s, n1s, d.send_slot[0].p, d.send_slot[1].p, rec, rs, shift_l, shift_r,
-                                                   sb[0], sb[1]);
+    auto post = [&](int t, int want, const double2 *rec, int what) {
+        k_dom_post<<<(what & 2) ? post_grid : 1, MD_BLOCK, 0, st>>>(ctx->n > 0 ? ctx->nblk : 0, ctx->partials.p, want, d.kuw_dev,
+                                                                    ctx->scal.p, t, n0s, n1s, d.send_slot[0].p, d.send_slot[1].p,
+                                                                    rec, rs, shift_l, shift_r, sb[0], sb[1], what);
     };
+    // MDHIP_DOM_OVERLAP=1: the record exchange overlaps the interior tiles.  Off by default: with ONE rank (the only
+    // configuration this code has been timed in) the exchange is a local copy and the two extra stream hand-overs per step
+    // cost more than it hides -- 0.231 against 0.199 ms/step, profiles/r02_slab_overlap_world1.txt; DESIGN.md section 6.
+    const char *ov = getenv("MDHIP_DOM_OVERLAP");
+    const bool overlap = ov && ov[0] == '1' && d.n_tiles_i > 0 && d.n_tiles_b + d.n_tiles_i == ctx->nblk;
+    if (overlap && !d.stream_i) {
+        // (a priority of its own: the runtime then gives it a hardware queue of its own, so that the interior tiles
+        // really run beside the boundary stream's kernels)
+        int plo = 0, phi = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&plo, &phi));
+        HIPCHK(hipStreamCreateWithPriority(&d.stream_i, hipStreamNonBlocking, plo));
+        HIPCHK(hipEventCreateWithFlags(&d.ev_go, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&d.ev_int, hipEventDisableTiming));
+    }
     auto adopt = [&](int t, int want, double2 *rec, int finalize) {
         k_dom_adopt<<<adopt_grid, MD_BLOCK, 0, st>>>(n0r, n1r, d.xh_slot.p, rb[0], rb[1], rec, rs, planes,
                                                      ctx->sb[ctx->cur].pos.p, d.kuw_dev, want, nvt ? 1 : 0, d.a_nf, d.a_term1,
                                                      ctx->d_kt.p, ctx->d_r1.p, ctx->d_r2.p, ctx->scal.p, t, finalize);
     };
+    ctx->part = md_ctx::StepPart{}; // (a window that failed half-way may have left a part selected)
     // records of the state the window starts from: own particles from the arrays, the x-halo particles' from their owners
     fused_enter(ctx, dt);
-    post(-1, 0, ctx->rec[0].p); // (step -1 < every first_viol: packs; its sums are not used)
+    post(-1, 0, ctx->rec[0].p, 3); // (step -1 < every first_viol: packs; its sums are not used)
     dom_exchange_records(ctx, sb, rb);
     adopt(-1, 0, ctx->rec[0].p, 0);
     // MDHIP_DEBUG_DOM=1: wait after every stage and say so (finds the stage a rank is stuck in)
@@ -2884,23 +2953,56 @@ static int dom_run_window_fused(md_ctx *ctx, int64_t nsteps, double dt, int ense
         if (ctx->prune_on && ctx->inner_valid && d.w_prune_interval > 0 && ctx->steps_since_prune >= d.w_prune_interval)
             ctx->inner_valid = false;
         if (ctx->prune_on && !ctx->inner_valid) d.w_prune_steps.push_back((int)t);
-        if (ctx->n > 0) {
+        if (ctx->n > 0 && overlap) {
+            // boundary tiles first, on the main stream; the interior tiles on their own stream while the boundary
+            // particles' records are packed and travel; the sums (and so the all-reduce) wait for both
+            const bool prune_step = ctx->prune_on && !ctx->inner_valid;
+            if (prune_step) k_reset_d1<<<1, 1, 0, st>>>(ctx->scal.p, (int)t - 1);
+            HIPCHK(hipEventRecord(d.ev_go, st));
+            HIPCHK(hipStreamWaitEvent(d.stream_i, d.ev_go, 0));
+            prof_begin(ctx);
+            if (prune_step && ctx->prof_open) ctx->prof_prune_acc++;
+            ctx->part.list = d.tiles_b.p;
+            ctx->part.count = d.n_tiles_b;
+            ctx->part.stream = st;
+            ctx->part.last = false;
             launch_step(ctx, want != 0, dt, (int)t);
+            ctx->part.list = d.tiles_i.p;
+            ctx->part.count = d.n_tiles_i;
+            ctx->part.stream = d.stream_i;
+            ctx->part.last = true;
+            launch_step(ctx, want != 0, dt, (int)t);
+            ctx->part = md_ctx::StepPart{};
+            HIPCHK(hipEventRecord(d.ev_int, d.stream_i));
+            double2 *recB = ctx->rec[ctx->fz_a].p; // the set this step wrote
+            post((int)t, want, recB, 2);
+            dom_exchange_records(ctx, sb, rb);
+            HIPCHK(hipStreamWaitEvent(st, d.ev_int, 0));
+            prof_end(ctx); // (boundary tiles + pack + exchange, or the interior tiles: whichever took longer)
+            stage("step + exchange");
+            post((int)t, want, recB, 1);
+            g_rccl.check(g_rccl.AllReduce(d.kuw_dev, d.kuw_dev, 4, ncclFloat64, ncclSum, d.comm, st), "ncclAllReduce(K,U,W,viol)");
+            adopt((int)t, want, recB, 1);
+            stage("sums + all-reduce + adopt");
         } else {
-            ctx->fz_a ^= 1;
-            if (ctx->prune_on && !ctx->inner_valid) {
-                ctx->inner_valid = true;
-                ctx->steps_since_prune = 0;
+            if (ctx->n > 0) {
+                launch_step(ctx, want != 0, dt, (int)t);
+            } else {
+                ctx->fz_a ^= 1;
+                if (ctx->prune_on && !ctx->inner_valid) {
+                    ctx->inner_valid = true;
+                    ctx->steps_since_prune = 0;
+                }
             }
+            double2 *recB = ctx->rec[ctx->fz_a].p; // the set this step wrote
+            stage("step");
+            post((int)t, want, recB, 3);
+            g_rccl.check(g_rccl.AllReduce(d.kuw_dev, d.kuw_dev, 4, ncclFloat64, ncclSum, d.comm, st), "ncclAllReduce(K,U,W,viol)");
+            stage("post + all-reduce");
+            dom_exchange_records(ctx, sb, rb);
+            adopt((int)t, want, recB, 1);
+            stage("exchange + adopt");
         }
-        double2 *recB = ctx->rec[ctx->fz_a].p; // the set this step wrote
-        stage("step");
-        post((int)t, want, recB);
-        g_rccl.check(g_rccl.AllReduce(d.kuw_dev, d.kuw_dev, 4, ncclFloat64, ncclSum, d.comm, st), "ncclAllReduce(K,U,W,viol)");
-        stage("post + all-reduce");
-        dom_exchange_records(ctx, sb, rb);
-        adopt((int)t, want, recB, 1);
-        stage("exchange + adopt");
         ctx->st_steps += 1;
         ctx->steps_since_prune += 1;
     }

@@ -7,7 +7,7 @@ Compiles the device code to assembly (hipcc -S, gfx950), finds the innermost loo
 (k_step_tile<3, LJ, uniform, no energies, no prune> by default) and counts its vector instructions by class:
 fp64 full-rate (v_*_f64 except v_rcp), v_rcp_f64 (quarter rate: 4 slots), 32-bit VALU (half a slot: the SIMD
 issues a wave64 32-bit op in 2 cycles, an fp64 op in 4), LDS and global memory instructions.  One loop iteration
-handles MD_UNROLL = 8 candidates."""
+handles MD_UNROLL = 8 candidates (16 when the compiler unrolls the loop once more: counted from the LDS reads)."""
 import os
 import re
 import subprocess
@@ -52,6 +52,8 @@ for s in hot:
     elif t.startswith("s_"):
         cls["salu"] += 1
 slots = cls["fp64"] + 4 * cls["rcp64"] + 0.5 * cls["valu32"]
+# three ds_read_b64 per candidate (x, y, z): the compiler may have unrolled the source loop (8 candidates) further
+cands = cls["lds"] / 3.0
 print("kernel", prefix)
-print("hot-path loop instructions per iteration (8 candidates; the rare exact re-decision blocks excluded):", cls)
-print("fp64-rate issue slots per iteration: %.1f   per candidate: %.2f" % (slots, slots / 8))
+print("hot-path loop instructions per machine-loop iteration (%g candidates; the rare exact re-decision blocks excluded):" % cands, cls)
+print("fp64-rate issue slots per iteration: %.1f   per 8 candidates: %.1f   per candidate: %.2f" % (slots, 8 * slots / cands, slots / cands))

@@ -43,6 +43,7 @@ def _launch(nproc, env_extra, port):
     sys.stdout.write(out[-3000:])
     sys.stderr.write(err[-3000:])
     assert p.returncode == 0, "slab-decomposed run disagrees with the single-handle run"
+    return err
 
 
 @pytest.mark.parametrize("nproc,nvt,stage,mode", [
@@ -73,6 +74,9 @@ def _launch(nproc, env_extra, port):
     # diameters exercise the 4-plane records, and the classic window sequence stays covered with the switch off
     (2, 1, "device", "shim-native-prune-poly"), (3, 0, "device", "shim-native-poly"),
     (2, 1, "device", "shim-native-prune-classic"), (1, 1, "", "nccl-native-prune-classic"),
+    # MDHIP_DOM_OVERLAP=1: boundary tiles first, the interior tiles on a second stream while the records travel
+    # (110592 particles: slabs of 24.9, wide enough for tiles that touch neither face)
+    (2, 1, "device", "shim-native-prune-big-overlap"), (1, 1, "", "nccl-native-prune-overlap"),
 ])
 def test_slab_decomposition_matches_single_gpu(nproc, nvt, stage, mode):
     # N=8000 -> L=20.7: 2 slabs of 10.4, 3 slabs of 6.9 (>= 2 cells each); kT=2 and dt=0.002 make
@@ -83,8 +87,9 @@ def test_slab_decomposition_matches_single_gpu(nproc, nvt, stage, mode):
            "MDHIP_RCCL_PATH": _build_shim() if mode.startswith("shim") else "",
            "DOM_PRUNE": "1" if "prune" in mode else "0", "DOM_STEPS": "120" if "prune" in mode else "60",
            "MDHIP_NO_FUSED_STEP": "1" if mode.endswith("classic") else "0",
+           "MDHIP_DOM_OVERLAP": "1" if mode.endswith("overlap") else "0",
            "DOM_POLY": "1" if mode.endswith("poly") else "0", "DOM_ELONG": "1" if mode.endswith("elong") else "0",
-           "DOM_N": "8232" if mode.endswith("elong") else ("27000" if mode.endswith("cfg4") else "8000"),   # 8232 = 2 * 4116 = 3 * 2744
+           "DOM_N": "8232" if mode.endswith("elong") else ("27000" if "cfg4" in mode else ("110592" if "big" in mode else "8000")),   # 8232 = 2 * 4116 = 3 * 2744
            "DOM_BACKEND": "nccl" if mode.startswith("nccl") else "gloo"}
     port = 29511 + nproc + 10 * nvt + (20 if stage else 0) + {"sync": 0, "async": 40, "nccl-sync": 80, "nccl-async": 120,
                                                                 "nccl-native": 160, "nccl-native-prune": 200, "async-prune": 240, "async-prune-poly": 280,
@@ -92,8 +97,16 @@ def test_slab_decomposition_matches_single_gpu(nproc, nvt, stage, mode):
                                                                 "shim-native": 440, "shim-native-prune": 480, "async-prune-cfg4": 520,
                                                                 "shim-native-prune-cfg4": 560, "shim-native-prune-poly": 600,
                                                                 "shim-native-poly": 640, "shim-native-prune-classic": 680,
-                                                                "nccl-native-prune-classic": 720}[mode]
-    _launch(nproc, env, port)
+                                                                "nccl-native-prune-classic": 720, "shim-native-prune-big-overlap": 760,
+                                                                "nccl-native-prune-overlap": 840}[mode]
+    if mode.endswith("overlap"):
+        env["MDHIP_DEBUG"] = "1"
+    err = _launch(nproc, env, port)
+    if mode.endswith("overlap"):
+        # the split launches really ran: some rank had interior tiles after a list build
+        import re
+        counts = [int(m) for m in re.findall(r"slab tiles: \d+ boundary, (\d+) interior", err)]
+        assert counts and max(counts) > 0, "no interior tiles: the overlapped window was not exercised"
 
 
 def test_slab_half_million_particles_per_rank():
