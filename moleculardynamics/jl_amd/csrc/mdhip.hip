@@ -499,13 +499,16 @@ void rebuild_t(md_ctx *c)
     DevState sn = c->dev(c->cur ^ 1);
 
     k_emit<D><<<nbs, MD_BLOCK, 0, st>>>(n_src, n_own_src, so, g, alive, c->img_off.p, c->keys_in.p, c->vals_in.p);
-    unsigned end_bit = (unsigned)(g.id_bits + g.cell_bits + 1);
+    // Only the (ghost bit, cell) digits are sorted -- three radix passes instead of five.  The sort is stable, so the
+    // particles of a cell keep the order they were emitted in (source-slot order), which is as deterministic as the
+    // id order the low digits would give.
+    unsigned begin_bit = (unsigned)g.id_bits, end_bit = (unsigned)(g.id_bits + g.cell_bits + 1);
     tmp_bytes = 0;
     HIPCHK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, c->keys_in.p, c->keys_out.p, c->vals_in.p, c->vals_out.p,
-                                     (size_t)next, 0u, end_bit, st));
+                                     (size_t)next, begin_bit, end_bit, st));
     c->sort_tmp.ensure(tmp_bytes);
     HIPCHK(rocprim::radix_sort_pairs(c->sort_tmp.p, tmp_bytes, c->keys_in.p, c->keys_out.p, c->vals_in.p,
-                                     c->vals_out.p, (size_t)next, 0u, end_bit, st));
+                                     c->vals_out.p, (size_t)next, begin_bit, end_bit, st));
     HIPCHK(hipMemsetAsync(c->cell_start.p, 0, sizeof(int32_t) * (c->ncell_ext + 1), st));
     HIPCHK(hipMemsetAsync(c->cell_end.p, 0, sizeof(int32_t) * (c->ncell_ext + 1), st));
     k_gather<D><<<nblocks(next), MD_BLOCK, 0, st>>>(n, (int)next, so, sn, g, c->keys_out.p, c->vals_out.p,
