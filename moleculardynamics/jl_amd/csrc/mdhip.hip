@@ -1454,7 +1454,7 @@ int md_upload(md_ctx *ctx, const double *x, const double *v, const double *f, co
                 uni = false;
                 break;
             }
-        ctx->uniform_sigma = uni;
+        ctx->uniform_sigma = uni && !getenv("MDHIP_PROBE_NONUNIFORM"); // (probe: time the 32-byte-record kernels on the bench workload)
         ctx->sigma_u = diameters[0];
         configure_potential(ctx);
     }
