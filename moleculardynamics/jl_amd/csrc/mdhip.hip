@@ -2383,7 +2383,8 @@ static void dom_classify_tiles(md_ctx *ctx)
 {
     auto &d = ctx->dom;
     d.n_tiles_b = d.n_tiles_i = 0;
-    if (!ctx->use_tiles || !ctx->virtual_ghosts || ctx->n <= 0) return;
+    const char *ov = getenv("MDHIP_DOM_OVERLAP"); // (only the overlapped window uses the classes)
+    if (!(ov && ov[0] == '1') || !ctx->use_tiles || !ctx->virtual_ghosts || ctx->n <= 0) return;
     hipStream_t st = ctx->stream;
     const int nb = ctx->nblk;
     d.tile_flag.ensure(nb);
