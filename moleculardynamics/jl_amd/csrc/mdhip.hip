@@ -964,6 +964,8 @@ void fused_enter(md_ctx *c, double dt)
     for (int w = 0; w < 2; ++w) c->rec[w].ensure(rec_stride(c) * planes);
     DevState s = c->dev(c->cur);
     double h2 = (dt * dt) / 2.0;
+    c->fz_a = 0;
+    if (c->nblk <= 0) return; // (a slab that owns no particle)
     if (c->dim == 3) {
         if (uni)
             k_fuse<3, true><<<c->nblk, MD_BLOCK, 0, c->stream>>>(n, s, c->rec[0].p, rec_stride(c), h2);
@@ -996,6 +998,10 @@ void fused_leave(md_ctx *c, bool apply_scale)
     DevState s = c->dev(c->cur);
     const double2 *rec = c->rec[c->fz_a].p;
     int ap = apply_scale ? 1 : 0;
+    if (c->nblk <= 0) {
+        c->fz_a = 0;
+        return;
+    }
     if (c->dim == 3) {
         if (uni)
             k_unfuse<3, true><<<c->nblk, MD_BLOCK, 0, c->stream>>>(n, s, rec, rec_stride(c), c->scal.p, ap);
