@@ -177,8 +177,64 @@ def fp64_probe(device):
     return None, None
 
 
+def spawn_ranks(nranks, cmd, env=None, timeout=None):
+    """Start `cmd` once per rank as a fresh child process (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT
+    set as torch.distributed.run would set them, one rank per GPU), relay rank 0's stdout to ours and return the
+    first non-zero exit status (0 if every rank succeeded).  The parent never touches the GPU: it only waits."""
+    import socket
+    base = dict(os.environ if env is None else env)
+    if "MASTER_PORT" not in base:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            base["MASTER_PORT"] = str(s.getsockname()[1])
+    base.setdefault("MASTER_ADDR", "127.0.0.1")
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    for r in range(nranks):
+        e = dict(base, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nranks), LOCAL_WORLD_SIZE=str(nranks),
+                 GROUP_RANK="0")
+        # rank 0's stdout is the job's stdout (the JSON line); the other ranks' stdout goes to stderr
+        procs.append(subprocess.Popen(cmd, env=e, stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    deadline = None if timeout is None else time.time() + timeout
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in pending:        # a failed rank leaves its peers stuck in a collective: end them
+                        q.terminate()
+            if deadline is not None and time.time() > deadline:
+                rc = rc or 124
+                for q in pending:
+                    q.kill()
+                break
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+            p.wait()
+    return rc
+
+
 def main():
     a = parse()
+    # --gpus N must run N ranks or fail.  Decided before anything touches a device (no torch import yet):
+    #   WORLD_SIZE unset, N > 1  -> this process becomes a launcher of N fresh children and exits with their status;
+    #   WORLD_SIZE set           -> we are one rank of a job somebody else launched; it has to be an N-rank job.
+    ws_env = os.environ.get("WORLD_SIZE")
+    if ws_env is None and a.gpus > 1:
+        sys.exit(spawn_ranks(a.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
+    if ws_env is not None and int(ws_env) != a.gpus:
+        print(f"[bench] --gpus {a.gpus} but WORLD_SIZE={ws_env}: refusing to report a different job size",
+              file=sys.stderr)
+        sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

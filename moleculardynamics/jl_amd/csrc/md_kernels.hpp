@@ -883,9 +883,27 @@ __global__ void __launch_bounds__(MD_TILE)
 // velocity-Verlet step).  PRUNE: the kept entries (d2 <= rin2) are appended to the lane's inner row as it goes.
 // One block of NQ candidates (NQ = 8 in the loop, 4 for a row's last half iteration): all LDS reads issued before
 // the first use, then the arithmetic.  o[q]: byte offsets of the candidates' records in the tile's LDS image.
+// Prune steps: appending a kept candidate to the lane's inner row.  Four 16-bit entries of a row are one 8-byte word
+// (row_off).  The word is a shift register filled from the TOP -- acc = (acc >> 16) | (entry << 48), two v_alignbit_b32,
+// no shift by a lane-dependent amount -- so after four appends it reads e0 | e1 << 16 | e2 << 32 | e3 << 48 and goes out
+// as it is; nothing has to be cleared (the next four appends push the old entries out).  A row's last, partial word
+// (p = cin & 3 entries, sitting in the top p slots) is moved down by tile_prune_tail.  wp: the lane's next row word.
+__device__ __forceinline__ void prune_append(unsigned entry, unsigned long long *&wp, unsigned long long &acc, int &cin)
+{
+    unsigned lo = (unsigned)acc, hi = (unsigned)(acc >> 32);
+    lo = __builtin_amdgcn_alignbit(hi, lo, 16);
+    hi = __builtin_amdgcn_alignbit(entry, hi, 16);
+    acc = ((unsigned long long)hi << 32) | lo;
+    ++cin;
+    if ((cin & 3) == 0) {
+        *wp = acc;
+        wp += 64;
+    }
+}
+
 template <int D, int POT, bool UNIFORM, bool WANT_UW, bool PRUNE, int NQ>
 __device__ __forceinline__ void tile_pair_block(const unsigned char *smem, const unsigned (&o)[NQ], const double4 &pi,
-                                                const PotParams &pp, unsigned long long *rin64, double rin2,
+                                                const PotParams &pp, unsigned long long *&rin64, double rin2,
                                                 unsigned long long &acc, int &cin, double &fx, double &fy, double &fz,
                                                 double &us, double &ws, const uint16_t *remap8)
 {
@@ -928,6 +946,7 @@ __device__ __forceinline__ void tile_pair_block(const unsigned char *smem, const
         // One integer subtract and one integer compare per candidate instead of an fp64 compare; the rare
         // undecided ones (2.6e-4 per particle and step at this density) are re-decided exactly below.
         unsigned tmin = 0xffffffffu;
+        unsigned km = 0u; // prune steps: bit q = candidate q stays in the inner row
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             dxq[q] = xj[q] - pi.x;
@@ -936,21 +955,21 @@ __device__ __forceinline__ void tile_pair_block(const unsigned char *smem, const
             double d2 = dxq[q] * dxq[q];
             d2 = __builtin_fma(dyq[q], dyq[q], d2);
             d2 = __builtin_fma(dzq[q], dzq[q], d2);
-            if constexpr (PRUNE) {
-                if (d2 <= rin2) { // (padding entries are 1e100 away: they never survive)
-                    acc |= (unsigned long long)(remap8 ? (unsigned)remap8[o[q] >> 3] : o[q]) << (16 * (cin & 3)); // (inner halo: its own offsets)
-                    ++cin;
-                    if ((cin & 3) == 0) {
-                        rin64[(size_t)((cin >> 2) - 1) * 64] = acc;
-                        acc = 0ull;
-                    }
-                }
-            }
+            if constexpr (PRUNE) km |= (d2 <= rin2) ? (1u << q) : 0u; // (padding entries are 1e100 away: they never survive)
             int hi = __double2hiint(d2);
             unsigned t = (unsigned)hi - pp.c2_k;
             tmin = min(tmin, t);
             hi = ((int)t < 0) ? hi : 0x5fe00000;
             dm[q] = __hiloint2double(hi, __double2loint(d2));
+        }
+        // The appends come after ALL the distance chains: one `if` per candidate inside the loop above cuts it into
+        // eight basic blocks, each with its own dependent fp64 chain and nothing to overlap it with.  The empty asm makes
+        // the mask a value the compiler cannot see through -- otherwise it sinks every chain back in front of "its" branch.
+        if constexpr (PRUNE) {
+            asm volatile("" : "+v"(km));
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                if (km & (1u << q)) prune_append(remap8 ? (unsigned)remap8[o[q] >> 3] : o[q], rin64, acc, cin); // (inner halo: its own offsets)
         }
         if (__any(tmin <= 2u)) {
 #pragma unroll
@@ -988,15 +1007,8 @@ __device__ __forceinline__ void tile_pair_block(const unsigned char *smem, const
         if constexpr (D == 3) dz = zj[q] - pi.z;
         double d2 = d2_ref<D>(dx, dy, dz);
         if constexpr (PRUNE) {
-            if (d2 <= rin2) { // (padding entries are 1e100 away: they never survive)
-                // four 16-bit entries of a row are one 8-byte word (row_off): write it when it is full
-                acc |= (unsigned long long)(remap8 ? (unsigned)remap8[o[q] >> 3] : o[q]) << (16 * (cin & 3)); // (inner halo: its own offsets)
-                ++cin;
-                if ((cin & 3) == 0) {
-                    rin64[(size_t)((cin >> 2) - 1) * 64] = acc;
-                    acc = 0ull;
-                }
-            }
+            if (d2 <= rin2) // (padding entries are 1e100 away: they never survive)
+                prune_append(remap8 ? (unsigned)remap8[o[q] >> 3] : o[q], rin64, acc, cin); // (inner halo: its own offsets)
         }
         bool hit = d2 < pp.c2;
         double d2m = mask_d2(d2, hit);
@@ -1015,7 +1027,7 @@ __device__ __forceinline__ void tile_pair_block(const unsigned char *smem, const
 template <int D, int POT, bool UNIFORM, bool WANT_UW, bool PRUNE>
 __device__ __forceinline__ void tile_pair_loop(const unsigned char *smem, const ushort4 *row4,
                                                ushort4 (&jn)[MD_UNROLL / 4], int m_lane, int H,
-                                               const double4 &pi, const PotParams &pp, unsigned long long *rin64,
+                                               const double4 &pi, const PotParams &pp, unsigned long long *&rin64,
                                                double rin2, unsigned long long &acc, int &cin, double &fx, double &fy,
                                                double &fz, double &us, double &ws, const uint16_t *remap8 = nullptr)
 {
@@ -1061,17 +1073,19 @@ __device__ __forceinline__ void tile_prune_tail(DevState &s, Scalars *sc, int H 
 {
     constexpr int RS = UNIFORM ? 24 : 32;
     {
-        // pad the inner row to the wave's longest (a multiple of 4) with the sentinel record
+        // pad the inner row to the wave's longest (a multiple of 4) with the sentinel record.  rin64 = the lane's next
+        // word (prune_append); a partial last word holds its p entries in the TOP p slots: moved down, padding on top
         const unsigned long long sent = (unsigned long long)(H * RS);
         const unsigned long long sent4 = sent | (sent << 16) | (sent << 32) | (sent << 48);
         int mw = wave_max_i((cin + 3) & ~3);
         int g = cin >> 2;
         if (cin & 3) {
-            int sh = 16 * (cin & 3);
-            rin64[(size_t)g * 64] = acc | (sent4 << sh);
+            int p = cin & 3;
+            *rin64 = (acc >> (16 * (4 - p))) | (sent4 << (16 * p));
+            rin64 += 64;
             ++g;
         }
-        for (; g < (mw >> 2); ++g) rin64[(size_t)g * 64] = sent4;
+        for (; g < (mw >> 2); ++g, rin64 += 64) *rin64 = sent4;
         if (lane == 0) nmax_in[wt] = mw;
         // reference positions of the inner rows, largest displacement since the build
         double dd = 0.0;
@@ -1501,18 +1515,13 @@ __global__ void __launch_bounds__(MD_TILE)
     MD_SSTAMP(2);
     __syncthreads();
     MD_SSTAMP(3);
-    // prune step with an inner halo (see tile_inner_halo)
-    const uint16_t *remap8 = nullptr;
-    int Hsent = H;
-    if constexpr (PRUNE) {
-        if (halo_in)
-            Hsent = tile_inner_halo<D, UNIFORM>(smem, H, hl, bid, pi, active, rin2, halo_in, hcap_in, halo_in_count, sc, step,
-                                                &remap8);
-    }
+    // (no inner halo here: the box test of tile_inner_halo keeps 96 % of a tile's staged set, and the exact criterion --
+    // the records some inner row references, ~80 % -- was built and measured in round 3: -3 % on the ordinary step,
+    // +100 us on every prune step for the translation of the rows.  DESIGN.md section 3)
     double fx = 0.0, fy = 0.0, fz = 0.0, us = 0.0, ws = 0.0;
-    tile_pair_loop<D, POT, UNIFORM, WANT_UW, PRUNE>(smem, row4, jn, m, H, pi, pp, rin64, rin2, acc, cin, fx, fy, fz, us, ws, remap8);
+    tile_pair_loop<D, POT, UNIFORM, WANT_UW, PRUNE>(smem, row4, jn, m, H, pi, pp, rin64, rin2, acc, cin, fx, fy, fz, us, ws, nullptr);
     MD_SSTAMP(4);
-    if constexpr (PRUNE) tile_prune_tail<D, UNIFORM>(s, sc, Hsent, k, active, lane, wt, pi, rin64, nmax_in, acc, cin);
+    if constexpr (PRUNE) tile_prune_tail<D, UNIFORM>(s, sc, H, k, active, lane, wt, pi, rin64, nmax_in, acc, cin);
     double ke = 0.0;
     if (active) {
         const double fn[3] = {fx, fy, fz};

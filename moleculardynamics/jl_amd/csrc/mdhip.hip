@@ -389,9 +389,11 @@ void configure_grid(md_ctx *c)
 // threshold -- which is NOT r*r in general (sqrt(6.25 - 1 ulp) already rounds to 2.5).
 double sqrt_ge_threshold(double r)
 {
+    if (!(r > 0.0) || !std::isfinite(r)) return 0.0; // (rejected by md_set_potential; never loop on it)
     double t = r * r;
-    while (std::sqrt(t) >= r) t = std::nextafter(t, 0.0);
-    while (std::sqrt(t) < r) t = std::nextafter(t, INFINITY);
+    // r*r is within one ulp of the threshold: a handful of steps either way, bounded so that nothing can spin here
+    for (int i = 0; i < 64 && t > 0.0 && std::sqrt(t) >= r; ++i) t = std::nextafter(t, 0.0);
+    for (int i = 0; i < 64 && std::sqrt(t) < r; ++i) t = std::nextafter(t, INFINITY);
     return t;
 }
 
@@ -1040,17 +1042,14 @@ void launch_step_tpu(md_ctx *c, bool want_uw, double dt, int step)
     }
     // which halo image the launch stages: the outer one (prune steps, and whenever there is no inner halo), or the
     // inner one the last prune step left behind
-    const bool ih = c->allow_inner_halo && c->prune_on && c->hcap_in > 0;
+    // (a fused prune step builds no inner halo -- md_kernels.hpp, k_step_tile; inner rows left behind by a CLASSIC prune
+    // step with MDHIP_INNER_HALO=1 index the inner image, which the ordinary fused step then stages)
     const uint32_t *halo_p = c->halo.p;
     int halo_cap = c->hcap;
     const int32_t *halo_cnt = c->halo_count.p;
     size_t lds_bytes = c->tile_lds;
     uint32_t *hin_p = nullptr;
-    if (prune_step && ih) {
-        hin_p = c->halo_in.p;
-        lds_bytes = ((c->tile_lds + 15) & ~(size_t)15) + (c->tile_lds / 8 + 8) * 2; // + the offset translation table
-        c->inner_halo_live = true;
-    } else if (prune_step) {
+    if (prune_step) {
         c->inner_halo_live = false;
     } else if (use_inner && c->inner_halo_live) {
         halo_p = c->halo_in.p;
@@ -1358,6 +1357,9 @@ int md_set_potential(md_ctx *ctx, int kind, const double *params, int nparams)
     if (nparams < 0 || nparams > 8 || (nparams > 0 && !params)) throw HipError("md_set_potential: bad params");
     int need = (kind == MD_POT_LJ) ? 3 : (kind == MD_POT_PSEUDOHS ? 1 : (kind == MD_POT_LJ_MODIFIED ? 5 : 2));
     if (nparams < need) throw HipError("md_set_potential: too few parameters for this kind");
+    // (the LJ kinds' r_cut becomes a threshold on d^2: it has to be a positive finite number)
+    if ((kind == MD_POT_LJ || kind == MD_POT_LJ_MODIFIED) && !(std::isfinite(params[2]) && params[2] > 0.0))
+        throw HipError("md_set_potential: r_cut must be finite and > 0");
     for (int i = 0; i < 8; ++i) ctx->pp.p[i] = (i < nparams) ? params[i] : 0.0;
     if (kind == MD_POT_LJ_MODIFIED) {
         // the constructor's constants: src/potentials.jl:52-64 (from the struct's sigma and r_cut)

@@ -292,3 +292,37 @@ def test_triclinic_unit_cell_is_refused_through_initialize_state(tmp_path):
     x = np.random.default_rng(0).uniform(0, 10, (64, 3))
     with pytest.raises(md.MdhipError, match="orthorhombic"):
         md.initialize_state(params, str(tmp_path), cutoff=2.5, positions=x, diameters=np.ones(64), unitcell=cell)
+
+
+def test_bench_launcher_starts_one_process_per_rank(tmp_path):
+    """bench.py --gpus N with no WORLD_SIZE must BE an N-rank job: the launcher starts N fresh
+    children with the torch.distributed.run environment, relays rank 0's stdout and returns the first failure."""
+    import subprocess
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    child = ("import os,sys;r=os.environ['RANK'];"
+             "open(os.path.join(sys.argv[1],'rank'+r),'w').write(' '.join(os.environ[k] for k in "
+             "('RANK','LOCAL_RANK','WORLD_SIZE','MASTER_ADDR','MASTER_PORT','HSA_ENABLE_IPC_MODE_LEGACY')));"
+             "print('line from rank',r)")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    rc = bench.spawn_ranks(3, [sys.executable, "-c", child, str(tmp_path)], env=env, timeout=60)
+    assert rc == 0
+    seen = sorted(os.listdir(tmp_path))
+    assert seen == ["rank0", "rank1", "rank2"]
+    ports = set()
+    for r in range(3):
+        f = open(os.path.join(tmp_path, f"rank{r}")).read().split()
+        assert f[0] == str(r) and f[1] == str(r) and f[2] == "3" and f[3] == "127.0.0.1" and f[5] == "0"
+        ports.add(f[4])
+    assert len(ports) == 1 and int(ports.pop()) > 0
+    # a failing rank ends the job with its status (and its peers are not left behind)
+    bad = "import os,sys,time;r=int(os.environ['RANK']);sys.exit(7) if r==1 else time.sleep(30)"
+    t0 = __import__("time").time()
+    assert bench.spawn_ranks(2, [sys.executable, "-c", bad], env=env, timeout=60) == 7
+    assert __import__("time").time() - t0 < 20
+    # one rank of somebody else's job: the job size must be the --gpus asked for (no GPU is touched before the check)
+    e2 = dict(env, WORLD_SIZE="1", RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
+                       env=e2, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 2 and "WORLD_SIZE=1" in p.stderr
