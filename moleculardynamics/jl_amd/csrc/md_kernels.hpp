@@ -887,8 +887,12 @@ __global__ void __launch_bounds__(MD_TILE)
 // (row_off).  The word is a shift register filled from the TOP -- acc = (acc >> 16) | (entry << 48), two v_alignbit_b32,
 // no shift by a lane-dependent amount -- so after four appends it reads e0 | e1 << 16 | e2 << 32 | e3 << 48 and goes out
 // as it is; nothing has to be cleared (the next four appends push the old entries out).  A row's last, partial word
-// (p = cin & 3 entries, sitting in the top p slots) is moved down by tile_prune_tail.  wp: the lane's next row word.
-__device__ __forceinline__ void prune_append(unsigned entry, unsigned long long *&wp, unsigned long long &acc, int &cin)
+// (p = cin & 3 entries, sitting in the top p slots) is moved down by tile_prune_tail.
+struct PruneRow {
+    unsigned char *base; // this WAVE's inner rows (uniform: the stores take it from scalar registers)
+    unsigned off;        // byte offset of the lane's next row word: lane * 8 + 512 per completed word
+};
+__device__ __forceinline__ void prune_append(unsigned entry, PruneRow &pr, unsigned long long &acc, int &cin)
 {
     unsigned lo = (unsigned)acc, hi = (unsigned)(acc >> 32);
     lo = __builtin_amdgcn_alignbit(hi, lo, 16);
@@ -896,14 +900,14 @@ __device__ __forceinline__ void prune_append(unsigned entry, unsigned long long 
     acc = ((unsigned long long)hi << 32) | lo;
     ++cin;
     if ((cin & 3) == 0) {
-        *wp = acc;
-        wp += 64;
+        *(unsigned long long *)(pr.base + pr.off) = acc;
+        pr.off += 512u;
     }
 }
 
 template <int D, int POT, bool UNIFORM, bool WANT_UW, bool PRUNE, int NQ>
 __device__ __forceinline__ void tile_pair_block(const unsigned char *smem, const unsigned (&o)[NQ], const double4 &pi,
-                                                const PotParams &pp, unsigned long long *&rin64, double rin2,
+                                                const PotParams &pp, PruneRow &rin64, double rin2,
                                                 unsigned long long &acc, int &cin, double &fx, double &fy, double &fz,
                                                 double &us, double &ws, const uint16_t *remap8)
 {
@@ -946,7 +950,7 @@ __device__ __forceinline__ void tile_pair_block(const unsigned char *smem, const
         // One integer subtract and one integer compare per candidate instead of an fp64 compare; the rare
         // undecided ones (2.6e-4 per particle and step at this density) are re-decided exactly below.
         unsigned tmin = 0xffffffffu;
-        unsigned km = 0u; // prune steps: bit q = candidate q stays in the inner row
+        double d2k[PRUNE ? NQ : 1]; // prune steps: the distances again, for the appends behind the chains
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             dxq[q] = xj[q] - pi.x;
@@ -955,7 +959,7 @@ __device__ __forceinline__ void tile_pair_block(const unsigned char *smem, const
             double d2 = dxq[q] * dxq[q];
             d2 = __builtin_fma(dyq[q], dyq[q], d2);
             d2 = __builtin_fma(dzq[q], dzq[q], d2);
-            if constexpr (PRUNE) km |= (d2 <= rin2) ? (1u << q) : 0u; // (padding entries are 1e100 away: they never survive)
+            if constexpr (PRUNE) d2k[q] = d2;
             int hi = __double2hiint(d2);
             unsigned t = (unsigned)hi - pp.c2_k;
             tmin = min(tmin, t);
@@ -964,12 +968,14 @@ __device__ __forceinline__ void tile_pair_block(const unsigned char *smem, const
         }
         // The appends come after ALL the distance chains: one `if` per candidate inside the loop above cuts it into
         // eight basic blocks, each with its own dependent fp64 chain and nothing to overlap it with.  The empty asm makes
-        // the mask a value the compiler cannot see through -- otherwise it sinks every chain back in front of "its" branch.
+        // the distances values the compiler cannot see through -- otherwise it sinks every chain back in front of "its" branch.
         if constexpr (PRUNE) {
-            asm volatile("" : "+v"(km));
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) asm volatile("" : "+v"(d2k[q]));
 #pragma unroll
             for (int q = 0; q < NQ; ++q)
-                if (km & (1u << q)) prune_append(remap8 ? (unsigned)remap8[o[q] >> 3] : o[q], rin64, acc, cin); // (inner halo: its own offsets)
+                if (d2k[q] <= rin2) // (padding entries are 1e100 away: they never survive)
+                    prune_append(remap8 ? (unsigned)remap8[o[q] >> 3] : o[q], rin64, acc, cin); // (inner halo: its own offsets)
         }
         if (__any(tmin <= 2u)) {
 #pragma unroll
@@ -1027,7 +1033,7 @@ __device__ __forceinline__ void tile_pair_block(const unsigned char *smem, const
 template <int D, int POT, bool UNIFORM, bool WANT_UW, bool PRUNE>
 __device__ __forceinline__ void tile_pair_loop(const unsigned char *smem, const ushort4 *row4,
                                                ushort4 (&jn)[MD_UNROLL / 4], int m_lane, int H,
-                                               const double4 &pi, const PotParams &pp, unsigned long long *&rin64,
+                                               const double4 &pi, const PotParams &pp, PruneRow &rin64,
                                                double rin2, unsigned long long &acc, int &cin, double &fx, double &fy,
                                                double &fz, double &us, double &ws, const uint16_t *remap8 = nullptr)
 {
@@ -1068,7 +1074,7 @@ __device__ __forceinline__ void tile_pair_loop(const unsigned char *smem, const 
 // displacement since the build.
 template <int D, bool UNIFORM>
 __device__ __forceinline__ void tile_prune_tail(DevState &s, Scalars *sc, int H /* sentinel slot of the image the inner rows index */, int k, bool active, int lane, int wt,
-                                                const double4 &pi, unsigned long long *rin64, int32_t *nmax_in,
+                                                const double4 &pi, PruneRow rin64, int32_t *nmax_in,
                                                 unsigned long long acc, int cin)
 {
     constexpr int RS = UNIFORM ? 24 : 32;
@@ -1081,11 +1087,11 @@ __device__ __forceinline__ void tile_prune_tail(DevState &s, Scalars *sc, int H 
         int g = cin >> 2;
         if (cin & 3) {
             int p = cin & 3;
-            *rin64 = (acc >> (16 * (4 - p))) | (sent4 << (16 * p));
-            rin64 += 64;
+            *(unsigned long long *)(rin64.base + rin64.off) = (acc >> (16 * (4 - p))) | (sent4 << (16 * p));
+            rin64.off += 512u;
             ++g;
         }
-        for (; g < (mw >> 2); ++g, rin64 += 64) *rin64 = sent4;
+        for (; g < (mw >> 2); ++g, rin64.off += 512u) *(unsigned long long *)(rin64.base + rin64.off) = sent4;
         if (lane == 0) nmax_in[wt] = mw;
         // reference positions of the inner rows, largest displacement since the build
         double dd = 0.0;
@@ -1235,7 +1241,10 @@ __global__ void __launch_bounds__(MD_TILE)
     int lane = threadIdx.x & 63;
     int wt = bid * (MD_TILE / 64) + (threadIdx.x >> 6);
     const ushort4 *row4 = (const ushort4 *)(nlist16 + ((size_t)wt * maxn) * 64) + lane;
-    unsigned long long *rin64 = PRUNE ? (unsigned long long *)(rows_in + ((size_t)wt * maxn) * 64) + lane : nullptr;
+    PruneRow rin64;
+    // (wt is the same for the whole wave: the base stays in scalar registers and the stores use it with a 32-bit offset)
+    rin64.base = PRUNE ? (unsigned char *)(rows_in + ((size_t)__builtin_amdgcn_readfirstlane(wt) * maxn) * 64) : nullptr;
+    rin64.off = (unsigned)lane * 8u;
     unsigned long long acc = 0ull;
     int cin = 0;
     int m = nmax_tile[wt];
@@ -1413,7 +1422,10 @@ __global__ void __launch_bounds__(MD_TILE)
     int lane = threadIdx.x & 63;
     int wt = bid * (MD_TILE / 64) + (threadIdx.x >> 6);
     const ushort4 *row4 = (const ushort4 *)(nlist16 + ((size_t)wt * maxn) * 64) + lane;
-    unsigned long long *rin64 = PRUNE ? (unsigned long long *)(rows_in + ((size_t)wt * maxn) * 64) + lane : nullptr;
+    PruneRow rin64;
+    // (wt is the same for the whole wave: the base stays in scalar registers and the stores use it with a 32-bit offset)
+    rin64.base = PRUNE ? (unsigned char *)(rows_in + ((size_t)__builtin_amdgcn_readfirstlane(wt) * maxn) * 64) : nullptr;
+    rin64.off = (unsigned)lane * 8u;
     unsigned long long acc = 0ull;
     int cin = 0;
     int m = nmax_tile[wt];
