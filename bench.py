@@ -35,6 +35,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 STEP_BYTES = {"nve": 332.0, "nvt": 380.0}   # algorithmic bytes per particle-step
+BINNING_BYTES = 32.0            # of STEP_BYTES: the cell binning (R x 24 + W cell id / permutation 8), done by the list build
 KICKDRIFT_BYTES = 160           # classic loop: R pos 32 + v 24 + f 24 + x1 24, W pos 32 + v 24
 FORCE_KERNEL_BYTES = 96.0       # classic loop's force kernel: R pos 32 + v 24, W f 24 + v 24
 # ISA-counted budget of the pair loop (scripts/isa_budget.py on k_step_tile<3, LJ, uniform, no energies>):
@@ -90,6 +91,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=40)
     ap.add_argument("--equil", type=int, default=200, help="untimed equilibration steps before warmup")
+    ap.add_argument("--frequency", type=int, default=0,
+                    help="k > 0: form U and W every k-th step inside the timed region (the reference's thermo cadence, "
+                         "src/simulation.jl:118-136: one md_run call of k steps per report, the last of them with energies); "
+                         "0 (default): on the timed region's last step only")
     return ap.parse_args()
 
 
@@ -369,7 +374,14 @@ def main():
     dev.profile(0 if os.environ.get("MDHIP_BENCH_NOPROF", "0") == "1" else 7)
     barrier()
     t0 = time.perf_counter()
-    uwk = run(a.steps, thermo=True)
+    if a.frequency > 0:
+        done = 0
+        while done < a.steps:
+            k = min(a.frequency, a.steps - done)
+            uwk = run(k, thermo=True)
+            done += k
+    else:
+        uwk = run(a.steps, thermo=True)
     barrier()
     el = time.perf_counter() - t0
     st1 = dev.stats()
@@ -381,24 +393,39 @@ def main():
         el = float(t.item())
 
     value = total_particles * a.steps / el
-    launches = max(1, st1["force_launches"])
-    kern_ms = st1["force_ms"] / launches
     fused = bool(st1.get("fused", 0))
     step_bytes = STEP_BYTES[ensemble]
-    # the dominant kernel: fused loop -> k_step_tile IS the step (all of SURVEY.md section 8(d)'s per-particle-step
-    # bytes pass through it); classic loop -> k_force_tile with its own 96 B per particle
-    per_particle = step_bytes if fused else FORCE_KERNEL_BYTES
+    # Kernel durations of the timed region: every prune-step launch is timed, the ordinary launches every 7th.  The
+    # roofline object's kernel_ms is the CALL-WEIGHTED average over both kinds, weighted with the numbers of ordinary and
+    # prune steps the timed region actually ran.
+    n_ord_timed = max(1, st1["force_launches"])
+    ord_ms = st1["force_ms"] / n_ord_timed
+    n_prune_timed = st1.get("prune_launches_timed", 0)
+    prune_ms = (st1.get("prune_ms", 0.0) / n_prune_timed) if n_prune_timed > 0 else None
+    prunes_region = st1["prunes"] - st0["prunes"]
+    steps_region = a.steps
+    if prune_ms is not None and prunes_region > 0:
+        kern_ms = (ord_ms * max(0, steps_region - prunes_region) + prune_ms * prunes_region) / steps_region
+    else:
+        kern_ms = ord_ms
+    launches = n_ord_timed + n_prune_timed
+    rebuilds_region = st1["rebuilds"] - st0["rebuilds"]
+    rebuild_ms = (st1.get("rebuild_ms", 0.0) / st1["rebuilds_timed"]) if st1.get("rebuilds_timed", 0) > 0 else None
+    # the dominant kernel: fused loop -> k_step_tile is the whole step EXCEPT the cell binning (32 B per particle of
+    # SURVEY.md section 8(d)'s figure: R x 24 + W cell id / permutation 8), which the list build does every ~41 steps and
+    # this kernel never moves; classic loop -> k_force_tile with its own 96 B per particle
+    per_particle = (step_bytes - BINNING_BYTES) if fused else FORCE_KERNEL_BYTES
     achieved = (per_particle * n_local) / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
     traffic, traffic_src = (None, None)
     if not use_domain and n_arg == 1048576:
         traffic, traffic_src = measured_traffic()
     # fp64-VALU co-roofline (SURVEY.md section 8(d) asks for both): issue slots the pair loop needs for the row
     # entries it walks, against the measured v_fma_f64 rate of this GPU
-    pr = st1.get("prune_launches_timed", 0)
+    pr = n_prune_timed
     walked = None
     if st1.get("walked_inner", 0) > 0 or st1.get("walked_outer", 0) > 0:
         w_in = st1["walked_inner"] if st1["walked_inner"] > 0 else st1["walked_outer"]
-        walked = (w_in * (launches - pr) + st1["walked_outer"] * pr) / launches
+        walked = (w_in * max(0, steps_region - prunes_region) + st1["walked_outer"] * prunes_region) / steps_region
     probe_slots, probe_gf = fp64_probe(local_rank) if rank == 0 else (None, None)
     valu = None
     if walked and kern_ms > 0:
@@ -449,7 +476,8 @@ def main():
             "max_tile_halo": st1["max_halo"],
             # the reference accumulates U and W every step; here they are formed on reporting steps only (identical
             # outputs at `frequency` cadence).  The energy-reporting variant of the kernel is ~25 % slower.
-            "energies_every_step": False,
+            "energies_every_step": a.frequency == 1,
+            "thermo_frequency": a.frequency if a.frequency > 0 else a.steps,
         },
         "roofline": {
             "bound": "hbm",
@@ -463,11 +491,20 @@ def main():
             "traffic_source": traffic_src,
             "traffic_GBps": (traffic / (kern_ms * 1e-3) / 1e9) if (traffic and kern_ms > 0) else None,
             "kernel": ("k_step_tile (drift folded into the halo staging, pair forces, both half-kicks, KE partials)" if fused
-                       else "k_force_tile (pair forces + second half-kick + KE partials)") + "; average over ordinary and prune steps",
+                       else "k_force_tile (pair forces + second half-kick + KE partials)")
+                      + "; kernel_ms = call-weighted average over the timed region's ordinary and prune launches "
+                        "(every prune launch timed, every 7th ordinary one).  The north-star number is step_roofline "
+                        "(whole step, list maintenance included), not this object",
             "kernel_ms": kern_ms,
+            "ordinary_ms": ord_ms,
+            "prune_ms": prune_ms,
+            "ordinary_steps_in_timed_region": max(0, steps_region - prunes_region),
+            "prune_steps_in_timed_region": prunes_region,
             "kernel_launches": launches,
             "prune_launches": pr,
             "algorithmic_bytes_per_particle": per_particle,
+            "bytes_note": ("SURVEY.md 8(d)'s per-particle-step figure minus the 32 B of cell binning the kernel does not move"
+                           if fused else "the force kernel's own share"),
             "bytes_per_launch": per_particle * n_local,
             "kernel_sources_sha256_16": kernel_hash(),
         },
@@ -481,9 +518,19 @@ def main():
             "frac": (KICKDRIFT_BYTES * n_local) / max(1e-12, st1["kickdrift_ms"] / max(1, st1["kickdrift_launches"]) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
         } if st1["kickdrift_launches"] > 0 else None,
         "step_roofline": {
+            "headline": True,
             "algorithmic_bytes_per_particle_step": step_bytes,
             "achieved_GBps": value / world * step_bytes / 1e9,
             "frac_of_8TBps": value / world * step_bytes / 1e9 / HBM_PEAK_GBPS,
+            "target_frac": 0.40,
+        },
+        # where the timed region went (per step, ms): kernels as timed above, list builds from the library's own events
+        "step_breakdown_ms": {
+            "ordinary_kernel": ord_ms, "prune_kernel": prune_ms,
+            "list_build": rebuild_ms, "list_builds_in_timed_region": rebuilds_region,
+            "list_build_per_step": (rebuild_ms * rebuilds_region / steps_region) if rebuild_ms is not None else None,
+            "kernels_per_step": kern_ms,
+            "wall_per_step": el * 1e3 / a.steps,
         },
         "thermo_last_step": {"U_per_particle": uwk[0] / total_particles, "T": 2.0 * uwk[2] / nf, "W": uwk[1]},
     }

@@ -144,7 +144,7 @@ typedef struct {
     int64_t n_ghost;        /* periodic ghost copies in the last build */
     int64_t max_neighbors;  /* neighbour-list row capacity */
     double avg_neighbors;   /* mean list length of the last build (candidates/particle) */
-    int64_t force_launches; /* force-kernel launches timed since md_profile(ctx,1) */
+    int64_t force_launches; /* ORDINARY force / step kernel launches timed since md_profile(ctx, k) (every k-th one) */
     double force_ms;        /* their summed duration, HIP events on the handle's stream */
     int64_t max_halo;       /* largest per-tile halo (LDS-staged neighbours) of the last build */
     int64_t tiled;          /* 1 if the LDS-tiled force kernel is in use, 0 if the global-gather one */
@@ -155,7 +155,12 @@ typedef struct {
                                kick-drift / force sequence */
     int64_t walked_outer;   /* row entries one launch over the OUTER rows walks (wave-padded, summed over particles) */
     int64_t walked_inner;   /* ... over the current INNER rows (0: none valid): the pair evaluations an ordinary step issues */
-    int64_t prune_launches_timed; /* how many of the timed force/step launches were prune steps */
+    int64_t prune_launches_timed; /* PRUNE-step launches timed since md_profile(ctx, k): every one, whatever the stride;
+                                     not counted in force_launches */
+    double prune_ms;        /* their summed duration */
+    int64_t rebuilds_timed; /* list builds timed since md_profile(ctx, k): every one, whatever the stride */
+    double rebuild_ms;      /* their summed duration, from the end of the last step before the build to the point where
+                               the next step can start (state conversion, sort, gather, rows, host waits included) */
 } md_stats;
 /* enable = 0: off; 1: HIP events around every force and kick-drift launch; k > 1: around every k-th launch of each
  * (an event record costs a few microseconds of device time: sampling keeps a timed run honest) */

@@ -32,7 +32,8 @@ class MdStats(C.Structure):
                 ("max_neighbors", C.c_int64), ("avg_neighbors", C.c_double), ("force_launches", C.c_int64),
                 ("force_ms", C.c_double), ("max_halo", C.c_int64), ("tiled", C.c_int64), ("prunes", C.c_int64),
                 ("kickdrift_launches", C.c_int64), ("kickdrift_ms", C.c_double), ("fused", C.c_int64),
-                ("walked_outer", C.c_int64), ("walked_inner", C.c_int64), ("prune_launches_timed", C.c_int64)]
+                ("walked_outer", C.c_int64), ("walked_inner", C.c_int64), ("prune_launches_timed", C.c_int64),
+                ("prune_ms", C.c_double), ("rebuilds_timed", C.c_int64), ("rebuild_ms", C.c_double)]
 
 
 class MdhipError(RuntimeError):

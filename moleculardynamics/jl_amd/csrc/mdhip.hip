@@ -221,6 +221,10 @@ struct md_ctx {
     double prof_kd_ms_acc = 0.0;
     int64_t prof_kd_launch_acc = 0;
     int64_t prof_prune_acc = 0;   // timed force/step launches that were prune steps
+    double prof_prune_ms_acc = 0.0;
+    double prof_rebuild_ms_acc = 0.0;
+    int64_t prof_rebuild_acc = 0;
+    bool prof_cur_prune = false;  // the launch being timed is a prune step
     bool last_run_fused = false;
     // launch_step over a subset of the tiles (slab windows: boundary tiles ahead of the interior ones)
     struct StepPart {
@@ -674,7 +678,8 @@ void rebuild(md_ctx *c)
 void prof_begin(md_ctx *c, int tag = 0)
 {
     if (!c->prof) return;
-    c->prof_open = (c->prof_seen[tag]++ % c->prof_stride) == 0;
+    // (tags 2, 3 -- list builds, prune steps: every one is timed; the stride thins out only the ordinary launches)
+    c->prof_open = tag >= 2 || (c->prof_seen[tag]++ % c->prof_stride) == 0;
     if (!c->prof_open) return;
     if (c->prof_used >= c->prof_ev.size()) {
         if (c->prof_ev.size() >= 8192) return;
@@ -705,6 +710,12 @@ void prof_collect(md_ctx *c)
         if (c->prof_tag[i] == 1) {
             c->prof_kd_ms_acc += ms;
             c->prof_kd_launch_acc++;
+        } else if (c->prof_tag[i] == 2) {
+            c->prof_rebuild_ms_acc += ms;
+            c->prof_rebuild_acc++;
+        } else if (c->prof_tag[i] == 3) {
+            c->prof_prune_ms_acc += ms;
+            c->prof_prune_acc++;
         } else {
             c->prof_ms_acc += ms;
             c->prof_launch_acc++;
@@ -773,8 +784,7 @@ void launch_force_tpu(md_ctx *c, bool want_uw, bool kick, double dt, int step, i
                                                    c->nlist16_in.p, c->nmax_tile_in.p, rin * rin,                   \
                                                    c->dbg_stamps.p, hin_p, c->hcap_in, c->halo_in_count.p);         \
     } while (0)
-    prof_begin(c);
-    if (prune_step && c->prof_open) c->prof_prune_acc++;
+    prof_begin(c, prune_step ? 3 : 0);
     if (c->use_tiles) {
         if (prune_step) {
             if (want_uw)
@@ -1084,8 +1094,7 @@ void launch_step_tpu(md_ctx *c, bool want_uw, double dt, int step)
                                                    c->nmax_tile_in.p, rin * rin, c->dbg_stamps.p, hin_p,            \
                                                    c->hcap_in, c->halo_in_count.p, c->part.list);                   \
     } while (0)
-    if (whole) prof_begin(c);
-    if (whole && prune_step && c->prof_open) c->prof_prune_acc++;
+    if (whole) prof_begin(c, prune_step ? 3 : 0);
     if (prune_step) {
         if (want_uw)
             LS(true, true);
@@ -1606,10 +1615,12 @@ int md_run(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, double tau, dou
     };
     // list build at a step boundary of the fused loop: records -> state arrays, build (permutes them), -> records
     auto fused_rebuild = [&]() {
+        prof_begin(ctx, 2);
         fused_leave(ctx, false);
         rebuild(ctx);
         fused = fused_available(ctx);
         if (fused) fused_enter(ctx, dt);
+        prof_end(ctx);
     };
     if (ctx->skin <= 0.0) {
         // literal reference cadence: a fresh linked-cell build every step
@@ -2061,6 +2072,9 @@ int md_profile(md_ctx *ctx, int enable)
         ctx->prof_kd_ms_acc = 0.0;
         ctx->prof_kd_launch_acc = 0;
         ctx->prof_prune_acc = 0;
+        ctx->prof_prune_ms_acc = 0.0;
+        ctx->prof_rebuild_acc = 0;
+        ctx->prof_rebuild_ms_acc = 0.0;
     }
     API_END
 }
@@ -2106,6 +2120,9 @@ int md_get_stats(md_ctx *ctx, md_stats *out)
         }
     }
     out->prune_launches_timed = ctx->prof_prune_acc;
+    out->prune_ms = ctx->prof_prune_ms_acc;
+    out->rebuilds_timed = ctx->prof_rebuild_acc;
+    out->rebuild_ms = ctx->prof_rebuild_ms_acc;
     API_END
 }
 
@@ -2972,8 +2989,7 @@ static int dom_run_window_fused(md_ctx *ctx, int64_t nsteps, double dt, int ense
             if (prune_step) k_reset_d1<<<1, 1, 0, st>>>(ctx->scal.p, (int)t - 1);
             HIPCHK(hipEventRecord(d.ev_go, st));
             HIPCHK(hipStreamWaitEvent(d.stream_i, d.ev_go, 0));
-            prof_begin(ctx);
-            if (prune_step && ctx->prof_open) ctx->prof_prune_acc++;
+            prof_begin(ctx, prune_step ? 3 : 0);
             ctx->part.list = d.tiles_b.p;
             ctx->part.count = d.n_tiles_b;
             ctx->part.stream = st;
