@@ -127,3 +127,101 @@ def cutoff_dimers(target, n_side=8, spacing=9.0, seed=99):
     n = x.shape[0]
     return dict(n=n, dim=3, box=np.full(3, L), x=x, v=np.zeros_like(x), f=np.zeros_like(x),
                 img=np.zeros((n, 3), dtype=np.int32), diam=np.ones(n), cat=np.array(cats))
+
+
+# ---------------------------------------------------------------------------------------------
+# The same across a periodic face.  The full-neighbour kernels evaluate a pair from both ends, and across a face the two
+# ends see different roundings of the same separation: from particle a's side the neighbour is b's translated image,
+# fl(fl(x_b + s L) - x_a); from b's side it is a's, fl(fl(x_a - s L) - x_b).  x + L rounds at ulp(L)/2 when x is small, so
+# the two squared separations differ by up to ~2 r ulp(L) (tens of ulps of d2 at L ~ 60).  The reference (CellListMap)
+# visits the pair once; the oracle restates it as: the particle with the LARGER index is the translated one.
+# ---------------------------------------------------------------------------------------------
+def face_d2_forms(a, b, L):
+    """(oracle form, other end's form) of the squared minimum-image separation of a (smaller index) and b, reference
+    arithmetic (every product and sum rounded, left to right)."""
+    do, db = [], []
+    for c in range(3):
+        d0 = float(b[c]) - float(a[c])
+        s = -1.0 if d0 > 0.5 * L else (1.0 if d0 < -0.5 * L else 0.0)
+        do.append((float(b[c]) + s * L) - float(a[c]))
+        db.append((float(a[c]) - s * L) - float(b[c]))
+    return (do[0] * do[0] + do[1] * do[1]) + do[2] * do[2], (db[0] * db[0] + db[1] * db[1]) + db[2] * db[2]
+
+
+def cross_face_dimers(target, L=63.0, seed=4711):
+    """Isolated dimers straddling a periodic face (m = 0, 1, 2 in turn) or an edge (two faces), squared separation
+    steered in ulps into category k % 5 relative to `target` (accept iff d2 <= target):
+      0  oracle form <= target <  other end's form     (the two ends of the pair decide differently)
+      1  other end's form <= target <  oracle form
+      2  oracle form == target
+      3  oracle form == nextafter(target, +inf)
+      4  oracle form within 64 ulp of target, unsteered
+    Particle 2k (the smaller index) sits just inside the low face, 2k+1 just inside the high face.
+    Returns dict(x, box, n, cat, ...) as cutoff_dimers does."""
+    rng = np.random.default_rng(seed)
+    up = np.nextafter(target, np.inf)
+    sites = [13.5 + 9.0 * i for i in range(5)]
+    places = []        # (main axis, second crossing axis or None, coordinates of the free axes)
+    for m in range(3):
+        f, t = (m + 1) % 3, (m + 2) % 3
+        for u in sites:
+            for w in sites:
+                places.append((m, None, {f: u, t: w}))
+    for m in range(3):
+        f, t = (m + 1) % 3, (m + 2) % 3
+        for u in sites:
+            places.append((m, t, {f: u}))
+    xs, cats = [], []
+    for k, (m, t2, free) in enumerate(places):
+        f = (m + 1) % 3
+        t = (m + 2) % 3
+        want = k % 5
+        got = -1
+        for _attempt in range(60):
+            th = rng.uniform(0.25, 1.1)
+            dyf = rng.uniform(2e-3, 2e-2) * rng.choice([-1.0, 1.0])
+            rr = np.sqrt(max(target - dyf * dyf, 0.0))
+            rm, rt = rr * np.cos(th), rr * np.sin(th)           # components along m (crosses its face) and t
+            a = np.zeros(3)
+            b = np.zeros(3)
+            a[m] = rng.uniform(0.02, 0.6 * rm)
+            b[m] = a[m] - rm + L                                 # image of a[m] - rm
+            a[f] = free[f] + rng.uniform(-0.25, 0.25)
+            b[f] = a[f] + dyf
+            if t2 is None:
+                a[t] = free[t] + rng.uniform(-0.25, 0.25)
+                b[t] = a[t] + rt
+            else:                                               # the t component crosses its face too
+                a[t] = rng.uniform(0.02, 0.6 * rt)
+                b[t] = a[t] - rt + L
+            # coarse: nudge b[t] until the oracle form is within a few ulp; fine: scan b[f] (never translated)
+            for _it in range(400):
+                ro, _ = face_d2_forms(a, b, L)
+                if abs(ro - target) <= 4 * (up - target):
+                    break
+                grow = ro < target                               # need a larger |separation along t|
+                sep_sign = 1.0 if t2 is None else -1.0           # b[t] - a[t] (minimum image) is +rt, or b[t] ~ L - ...: moving b[t] up shrinks it
+                b[t] = np.nextafter(b[t], np.inf if (grow == (sep_sign > 0)) else -np.inf)
+            found = False
+            base = b[f]
+            for kk in sorted(range(-3000, 3001), key=abs):
+                bb = b.copy()
+                bb[f] = base + kk * np.spacing(base)
+                ro, rb = face_d2_forms(a, bb, L)
+                ok = ((want == 0 and ro <= target < rb) or (want == 1 and rb <= target < ro) or
+                      (want == 2 and ro == target) or (want == 3 and ro == up) or
+                      (want == 4 and abs(ro - target) <= 64 * (up - target)))
+                if ok:
+                    b = bb
+                    found = True
+                    break
+            if found:
+                got = want
+                break
+        xs.append(a)
+        xs.append(b)
+        cats.append(got)
+    x = np.array(xs)
+    n = x.shape[0]
+    return dict(n=n, dim=3, box=np.full(3, L), x=x, v=np.zeros_like(x), f=np.zeros_like(x),
+                img=np.zeros((n, 3), dtype=np.int32), diam=np.ones(n), cat=np.array(cats))
