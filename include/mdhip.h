@@ -171,10 +171,14 @@ int md_get_stats(md_ctx *ctx, md_stats *out);
  * Slab decomposition: one handle per GPU, each owning the particles of one slab of the x axis
  * (new relative to the reference, which is single-process).  y and z
  * stay periodic inside the handle; x-direction ghosts are copies of the neighbour slabs'
- * particles.  The library packs and unpacks; the CALLER moves the buffers between the ranks
- * (moleculardynamics/jl_amd/domain.py does it with torch.distributed: RCCL over xGMI).
+ * particles.  Two ways to move the data between the ranks:
+ *   * the library does it itself on its own RCCL communicator (md_dom_comm_init, then md_dom_rebuild for a whole
+ *     list build and md_dom_run_window for a window of steps: no host code between the phases) -- the default of
+ *     moleculardynamics/jl_amd/domain.py and bench.py with one GPU per rank;
+ *   * the library only packs and unpacks and the CALLER moves the buffers (any transport: the phase-by-phase entry
+ *     points below; domain.py drives them through torch.distributed when the native transport is not available).
  *
- * A list build is the sequence  migrate_pack -> [exchange] -> migrate_unpack -> halo_pack ->
+ * Phase by phase, a list build is the sequence  migrate_pack -> [exchange] -> migrate_unpack -> halo_pack ->
  * [exchange] -> halo_unpack -> build ; a step is  step_begin -> [exchange] -> step_end .
  * side 0 = the left neighbour (rank-1 mod P), side 1 = the right neighbour.  A message sent
  * to side s arrives in the neighbour's receive buffer 1-s.  Record sizes in doubles:
@@ -239,7 +243,8 @@ int md_dom_async_end(md_ctx *ctx, int apply_pending_scale, int32_t *first_viol, 
  * the process).  Rank 0 obtains the 128-byte unique id and distributes it by any means; every rank then calls
  * md_dom_comm_init (collective; it ends with an all-reduce self-test).  md_dom_run_window = md_dom_async_begin
  * + nsteps x (step_a, all-reduce MIN, neighbour send/recv, step_b, all-reduce SUM, step_c) + md_dom_async_end;
- * report_last asks for the global U, W of the window's last step.  List builds stay with the caller.        */
+ * report_last asks for the global U, W of the window's last step.  List builds: md_dom_rebuild (below), or the
+ * phase-by-phase sequence with the caller's own transport.                                                       */
 int md_dom_comm_unique_id(const char *rccl_path, void *id128);
 int md_dom_comm_init(md_ctx *ctx, const char *rccl_path, const void *id128);
 /* The whole list-build sequence above (md_dom_migrate_pack ... md_dom_build) in ONE call, the neighbour exchanges (counts,
@@ -254,7 +259,13 @@ int md_dom_run_window(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, doub
  * collectives per step; what travels is the boundary particles' state records).  Then info[6] = 1 and, after a violation,
  * the state returned is that of the last complete step first_viol - 1: the caller refreshes the rows and resumes AT step
  * first_viol (no md_dom_forces call).  info[6] = 0: the classic sequence ran -- the violating step's drift is applied and
- * md_dom_forces completes it.                                                                                   */
+ * md_dom_forces completes it.
+ * A fused window refreshes the x-halo particles' state RECORDS, not their coordinates: until the next list build (or a
+ * classic step's exchange) md_dom_forces refuses to run -- it would read neighbour coordinates as of the last build.
+ * A failure of one rank inside a window aborts the communicator (its peers' collectives return an error instead of
+ * waiting); the handle needs md_dom_comm_init again.  Any call that fails inside a fused step loop (md_run,
+ * md_dom_run_window) leaves the handle's particle state incomplete: later calls that read it fail until md_upload /
+ * md_dom_upload provides x, v and f again.                                                                        */
 /* Inner rows (see md_set_inner_skin) on a slab handle.  Every rank must prune at the same steps, so the caller
  * plans the schedule from all-reduced quantities: prune_interval (md_dom_async_begin / md_dom_run_window) = steps
  * between prune steps inside a window (0 = none scheduled); info (md_dom_async_end / md_dom_run_window) returns {1 if the violating step was a prune step, this rank's d1 = max|x - x0| at

@@ -123,6 +123,9 @@ struct md_ctx {
         hipStream_t stream_i = nullptr; // the interior tiles' stream
         hipEvent_t ev_go = nullptr, ev_int = nullptr;
         DBuf<double> own_kuw;
+        // a fused window refreshes the x-halo particles' state RECORDS every step, not their pos[] entries: until the
+        // next list build (or a classic step's coordinate exchange) md_dom_forces would read stale neighbour coordinates
+        bool xhalo_pos_stale = false;
     } dom;
     double L[3] = {1, 1, 1};
     double rc = 0.0;       // list cutoff (CellListMap's cutoff)
@@ -235,6 +238,10 @@ struct md_ctx {
     } part;
 
     std::string err;
+    // A failure inside a fused step loop (between fused_enter and fused_leave) leaves the live state in the step
+    // records and whichever buffer set the ping-pong points at: pos / v / f are stale.  Every entry that reads the state
+    // refuses to go on until a full md_upload (x, v and f) replaces it.
+    bool state_invalid = false;
 
     DevState dev(int which)
     {
@@ -1172,6 +1179,22 @@ int fail(md_ctx *c, const char *what)
 
 } // namespace
 
+struct FusedScope { // md_run / slab windows: marks the handle's state invalid when the fused loop is left by an exception
+    md_ctx *c;
+    bool done = false;
+    ~FusedScope()
+    {
+        if (!done) c->state_invalid = true;
+    }
+};
+
+inline void require_state(md_ctx *c, const char *who)
+{
+    if (c->state_invalid)
+        throw HipError(std::string(who) + ": an earlier call failed inside the fused step loop and left the particle state "
+                                          "incomplete; upload x, v and f again (md_upload) before going on");
+}
+
 #define API_BEGIN                                                                                                   \
     if (!ctx) return fail(nullptr, "null handle");                                                                  \
     try {                                                                                                           \
@@ -1488,12 +1511,18 @@ int md_upload(md_ctx *ctx, const double *x, const double *v, const double *f, co
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st)); // host buffers are only borrowed for this call
     if (x || diameters) ctx->list_valid = false;
+    if (x && v && f) {
+        // a complete new state: whatever a failed step loop left behind is gone
+        ctx->state_invalid = false;
+        ctx->fz_a = 0;
+    }
     API_END
 }
 
 int md_download(md_ctx *ctx, double *x, double *v, double *f, int32_t *images)
 {
     API_BEGIN
+    require_state(ctx, "md_download");
     size_t nd = (size_t)ctx->n * ctx->dim;
     hipStream_t st = ctx->stream;
     ctx->io_x.ensure(nd);
@@ -1518,6 +1547,7 @@ int md_download(md_ctx *ctx, double *x, double *v, double *f, int32_t *images)
 int md_compute_forces(md_ctx *ctx, double *energy, double *virial)
 {
     API_BEGIN
+    require_state(ctx, "md_compute_forces");
     if (!ctx->list_valid) rebuild(ctx);
     launch_force(ctx, true, false, 0.0, -1, 1); // outer rows: always valid for the current positions
     launch_finalize(ctx, true, false, 1.0, 0.0, -1);
@@ -1531,6 +1561,7 @@ int md_compute_forces(md_ctx *ctx, double *energy, double *virial)
 int md_neighbor_pairs(md_ctx *ctx, int32_t *pairs, int64_t cap, int64_t *count)
 {
     API_BEGIN
+    require_state(ctx, "md_neighbor_pairs");
     if (cap < 0 || (cap > 0 && !pairs)) throw HipError("md_neighbor_pairs: bad output buffer");
     if (!ctx->list_valid) rebuild(ctx);
     hipStream_t st = ctx->stream;
@@ -1566,6 +1597,7 @@ int md_run(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, double tau, dou
            const double *r1, const double *r2, double *uwk)
 {
     API_BEGIN
+    require_state(ctx, "md_run");
     if (nsteps < 0) throw HipError("md_run: nsteps must be >= 0");
     if (nsteps > 0x3fffffff) throw HipError("md_run: nsteps too large for one call");
     if (ensemble != MD_NVE && ensemble != MD_NVT) throw HipError("md_run: unknown ensemble");
@@ -1600,6 +1632,8 @@ int md_run(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, double tau, dou
     // classic three-kernel sequence otherwise (slab handles, user potentials, rows that do not fit LDS, skin 0).
     bool fused = ctx->skin > 0.0 && fused_available(ctx);
     ctx->last_run_fused = fused;
+    FusedScope fscope{ctx};
+    fscope.done = !fused; // (the classic loop keeps the state in the arrays at every step boundary)
     if (fused) fused_enter(ctx, dt);
     auto step_part = [&](int t) {
         if (!fused) {
@@ -1617,9 +1651,13 @@ int md_run(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, double tau, dou
     auto fused_rebuild = [&]() {
         prof_begin(ctx, 2);
         fused_leave(ctx, false);
+        fscope.done = true; // (the arrays hold the state of the last completed step)
         rebuild(ctx);
         fused = fused_available(ctx);
-        if (fused) fused_enter(ctx, dt);
+        if (fused) {
+            fscope.done = false;
+            fused_enter(ctx, dt);
+        }
         prof_end(ctx);
     };
     if (ctx->skin <= 0.0) {
@@ -1840,6 +1878,7 @@ int md_run(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, double tau, dou
     if (fused) {
         // records -> state arrays, with the last step's pending rescale applied (src/thermostat.jl:43-45)
         fused_leave(ctx, true);
+        fscope.done = true;
         if (nvt) k_set_scale<<<1, 1, 0, st>>>(ctx->scal.p, 1.0);
     } else if (nvt) {
         // apply the last step's pending rescale (src/thermostat.jl:43-45) so the state the
@@ -1877,6 +1916,7 @@ int md_fire_minimize(md_ctx *ctx, int64_t max_steps, double tol, double dt_initi
                      double *f_rms)
 {
     API_BEGIN
+    require_state(ctx, "md_fire_minimize");
     if (ctx->dom.on) throw HipError("md_fire_minimize: not available on a slab-decomposition handle");
     if (max_steps < 0 || max_steps > 0x3ffffff0) throw HipError("md_fire_minimize: bad max_steps");
     if (!(dt_initial > 0.0) || !(dt_max >= dt_initial)) throw HipError("md_fire_minimize: need 0 < dt_initial <= dt_max");
@@ -1974,6 +2014,7 @@ int md_run_brownian(md_ctx *ctx, int64_t nsteps, double dt, double ktemp, uint64
                     int64_t virial_every, double *out)
 {
     API_BEGIN
+    require_state(ctx, "md_run_brownian");
     if (ctx->dom.on) throw HipError("md_run_brownian: not available on a slab-decomposition handle");
     if (nsteps < 0 || nsteps > 0x3ffffff0) throw HipError("md_run_brownian: bad nsteps");
     if (!(dt > 0.0) || !(ktemp > 0.0)) throw HipError("md_run_brownian: need dt > 0 and kT > 0");
@@ -2034,6 +2075,7 @@ int md_run_brownian(md_ctx *ctx, int64_t nsteps, double dt, double ktemp, uint64
 int md_kinetic(md_ctx *ctx, double *kinetic)
 {
     API_BEGIN
+    require_state(ctx, "md_kinetic");
     DevState s = ctx->dev(ctx->cur);
     if (ctx->dim == 3)
         k_ke_partials<3><<<ctx->nblk, MD_BLOCK, 0, ctx->stream>>>((int)ctx->n, s, ctx->partials.p);
@@ -2049,6 +2091,7 @@ int md_kinetic(md_ctx *ctx, double *kinetic)
 int md_scale_velocities(md_ctx *ctx, double sfac)
 {
     API_BEGIN
+    require_state(ctx, "md_scale_velocities");
     DevState s = ctx->dev(ctx->cur);
     if (ctx->dim == 3)
         k_scale_v<3><<<ctx->nblk, MD_BLOCK, 0, ctx->stream>>>((int)ctx->n, s, ctx->scal.p, sfac, 0);
@@ -2162,6 +2205,7 @@ int md_dom_upload(md_ctx *ctx, int64_t n_own, const int32_t *ids, const double *
                   const int32_t *images, const double *diameters)
 {
     API_BEGIN
+    if (x && v && f) ctx->state_invalid = false; // (a complete new state)
     dom_require(ctx);
     if (n_own < 0 || n_own > ctx->ncap) throw HipError("md_dom_upload: n_own exceeds the handle's capacity");
     if (n_own > 0 && (!ids || !x)) throw HipError("md_dom_upload: ids and x are required");
@@ -2205,6 +2249,7 @@ int md_dom_download(md_ctx *ctx, int64_t cap, int64_t *n_own, int32_t *ids, doub
                     int32_t *images)
 {
     API_BEGIN
+    require_state(ctx, "md_dom_download");
     dom_require(ctx);
     if (n_own) *n_own = ctx->n;
     if (cap < ctx->n) throw HipError("md_dom_download: output capacity is smaller than the owned count");
@@ -2454,6 +2499,7 @@ int md_dom_build(md_ctx *ctx)
     HIPCHK(hipStreamSynchronize(st));
     d.n_old = ctx->n;
     d.n_arr = 0;
+    d.xhalo_pos_stale = false;
     dom_classify_tiles(ctx);
     API_END
 }
@@ -2492,6 +2538,7 @@ int md_dom_step_end(md_ctx *ctx, double dt, int want_uw, double *uwk)
     API_BEGIN
     dom_require(ctx);
     auto &d = ctx->dom;
+    d.xhalo_pos_stale = false; // (the coordinates just received are unpacked below)
     hipStream_t st = ctx->stream;
     DevState s = ctx->dev(ctx->cur);
     int64_t off = 0;
@@ -2525,8 +2572,12 @@ int md_dom_step_end(md_ctx *ctx, double dt, int want_uw, double *uwk)
 int md_dom_forces(md_ctx *ctx, double dt, int kick, int want_uw, double *uwk)
 {
     API_BEGIN
+    require_state(ctx, "md_dom_forces");
     dom_require(ctx);
     if (!ctx->list_valid) throw HipError("md_dom_forces: no valid neighbour list");
+    if (ctx->dom.xhalo_pos_stale)
+        throw HipError("md_dom_forces: the x-halo coordinates are as of the last list build (a fused step window refreshes "
+                       "only the state records); call md_dom_rebuild / md_dom_build, or a classic step's exchange, first");
     if (ctx->n > 0) {
         launch_force(ctx, want_uw != 0, kick != 0, dt, -1);
         launch_finalize(ctx, want_uw != 0, false, 1.0, 0.0, -1);
@@ -2641,6 +2692,7 @@ int md_dom_step_b(md_ctx *ctx, double dt, int step, int want_uw)
 {
     API_BEGIN
     auto &d = ctx->dom;
+    d.xhalo_pos_stale = false; // (the coordinates just received are unpacked below)
     hipStream_t st = ctx->stream;
     DevState s = ctx->dev(ctx->cur);
     double *in[2];
@@ -2963,6 +3015,7 @@ static int dom_run_window_fused(md_ctx *ctx, int64_t nsteps, double dt, int ense
     };
     ctx->part = md_ctx::StepPart{}; // (a window that failed half-way may have left a part selected)
     // records of the state the window starts from: own particles from the arrays, the x-halo particles' from their owners
+    FusedScope fscope{ctx};
     fused_enter(ctx, dt);
     post(-1, 0, ctx->rec[0].p, 3); // (step -1 < every first_viol: packs; its sums are not used)
     dom_exchange_records(ctx, sb, rb);
@@ -2975,8 +3028,14 @@ static int dom_run_window_fused(md_ctx *ctx, int64_t nsteps, double dt, int ense
         HIPCHK(hipStreamSynchronize(st));
         fprintf(stderr, "[mdhip] rank %d window step %lld: %s done\n", d.rank, (long long)t_now, what);
     };
+    // MDHIP_DOM_FAIL="rank:step": this rank fails inside the window at that step (tests: its peers must error out through
+    // the aborted communicator, not wait for a collective that never comes)
+    int fail_rank = -1, fail_step = -1;
+    if (const char *e = getenv("MDHIP_DOM_FAIL")) (void)sscanf(e, "%d:%d", &fail_rank, &fail_step);
+    if (nsteps > 0) d.xhalo_pos_stale = true;
     for (int64_t t = 0; t < nsteps; ++t) {
         t_now = t;
+        if (d.rank == fail_rank && t == fail_step) throw HipError("md_dom_run_window: injected failure (MDHIP_DOM_FAIL)");
         const int want = (report_last && t == nsteps - 1) ? 1 : 0;
         // inner rows: the schedule (identical on every rank) is the caller's prune interval
         if (ctx->prune_on && ctx->inner_valid && d.w_prune_interval > 0 && ctx->steps_since_prune >= d.w_prune_interval)
@@ -3046,6 +3105,7 @@ static int dom_run_window_fused(md_ctx *ctx, int64_t nsteps, double dt, int ense
     }
     const bool swapped = ctx->fz_a != 0;
     fused_leave(ctx, nvt && apply_pending_scale && !violated);
+    fscope.done = true;
     if (swapped && n0r + n1r > 0)
         k_dom_copy_xhalo<<<nblocks(n0r + n1r), MD_BLOCK, 0, st>>>(n0r + n1r, d.xh_slot.p, ctx->sb[ctx->cur ^ 1].pos.p,
                                                                  ctx->sb[ctx->cur].pos.p);
@@ -3090,6 +3150,7 @@ int md_dom_run_window(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, doub
                       int64_t prune_interval, int32_t *first_viol, double *uwk, double *info)
 {
     API_BEGIN
+    require_state(ctx, "md_dom_run_window");
     dom_require(ctx);
     auto &d = ctx->dom;
     if (!d.comm) throw HipError("md_dom_run_window: no communicator (md_dom_comm_init first)");
@@ -3182,6 +3243,7 @@ int md_dom_set_scale(md_ctx *ctx, double scale)
 int md_dom_rebuild(md_ctx *ctx)
 {
     API_BEGIN
+    require_state(ctx, "md_dom_rebuild");
     dom_require(ctx);
     auto &d = ctx->dom;
     if (!d.comm) throw HipError("md_dom_rebuild: no communicator (md_dom_comm_init first)");

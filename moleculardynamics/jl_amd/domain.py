@@ -367,7 +367,11 @@ class DomainDevice:
 
         if getattr(self, "_native_ready", False):
             # the library's own communicator is up (run_native): the whole sequence in one call, exchanges on RCCL
-            self._chk(self._L.md_dom_rebuild(self._h)); lap()
+            try:
+                self._chk(self._L.md_dom_rebuild(self._h)); lap()
+            except Exception:
+                self._native_ready = False      # (a failed collective aborts the communicator: bind it again next time)
+                raise
             c = self.counts()
             self._nsend_halo, self._nrecv_halo = c["nsend_halo"], c["nrecv_halo"]
             self._bind_step_buffers()
@@ -528,9 +532,13 @@ class DomainDevice:
         L, h = self._L, self._h
 
         def window(wlen, dt, ensemble, tau, nf, arrs, nvt, ends_run, prune_interval, fv, uwk, info):
-            self._chk(L.md_dom_run_window(h, wlen, float(dt), int(ensemble), float(tau), nf, *arrs,
-                                          1 if ends_run else 0, 1 if ends_run else 0, int(prune_interval), C.byref(fv),
-                                          uwk, info))
+            try:
+                self._chk(L.md_dom_run_window(h, wlen, float(dt), int(ensemble), float(tau), nf, *arrs,
+                                              1 if ends_run else 0, 1 if ends_run else 0, int(prune_interval), C.byref(fv),
+                                              uwk, info))
+            except Exception:
+                self._native_ready = False      # (the library aborted its communicator: md_dom_comm_init again)
+                raise
 
         return self._run_planned(window, nsteps, dt, ensemble, tau, nf, ktemp, r1, r2)
 

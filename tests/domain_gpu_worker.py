@@ -63,6 +63,11 @@ def main():
         X0, V0, F0, I0 = d.gather_global()
         d.upload_global(s["x"], s["v"], s["f"], s["img"], s["diam"])
         d.builds = 0
+        if os.environ.get("DOM_SAFETY"):
+            # an over-confident planner (validity radii scaled up): the windows overrun the rows' validity, so displacement
+            # violations happen INSIDE the windows -- the device-side fallback of the fused window is exercised
+            d._rate, d._rate_known, d._safety = 0.0, False, float(os.environ["DOM_SAFETY"])
+            d._pruning, d._skins = bool(getattr(d, "_prune_req", False)), (0.0, 0.0)
         runner = {"0": d.run, "1": d.run_async, "native": d.run_native}[os.environ.get("DOM_ASYNC", "0")]
         Ue, We, Ke = runner(nsteps, dt, ens, 0.1, nf, kt, r1, r2)
         X, V, F, IM = d.gather_global()
@@ -93,6 +98,8 @@ def main():
             # md_dom_run_window took the fused step: in every window, unless some rank's tiles stopped fitting the LDS
             # at a list build (per-particle diameters: 32-byte records) and all ranks went on with the classic sequence
             ok &= stats[4][0] >= 1 and (stats[4][0] == stats[4][1] or os.environ.get("DOM_POLY", "0") == "1")
+        if os.environ.get("DOM_EXPECT_VIOL", "0") == "1":
+            ok &= stats[1] >= 1      # some window was cut short by a displacement violation
     flag = [ok]
     dist.broadcast_object_list(flag, src=0)
     dist.destroy_process_group()

@@ -5,6 +5,8 @@
 // two ranks (left and right neighbour are the same peer), the global violation flag, window skipping, prune steps --
 // runs with 2 and 3 real ranks.  libmdhip binds it exactly like RCCL: dlopen(path) + dlsym of the same symbols
 // (csrc/md_rccl.hpp).  Every call is synchronous: hipStreamSynchronize, host copy, exchange, copy back.
+// ncclCommAbort on any rank sets a shared flag that every blocked (and every later) call of every rank returns an error
+// on, as RCCL's does: the library's fail-fast path (DomAbortGuard) can be tested with real peers.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -29,6 +31,8 @@ struct Box { // single-producer single-consumer ring, src -> dst
 };
 struct Shared {
     std::atomic<int> bar_count, bar_gen;
+    std::atomic<int> aborted; // set by ncclCommAbort on ANY rank: every blocked or later call of every rank fails
+                              // (RCCL's behaviour after an abort: peers error out instead of hanging)
     double ar[MAXR][64];
     Box box[MAXR][MAXR];
 };
@@ -37,15 +41,19 @@ struct Comm {
     Shared *sh;
 };
 
-void barrier(Comm *c)
+bool barrier(Comm *c) // false: the communicator was aborted while waiting
 {
     int gen = c->sh->bar_gen.load();
     if (c->sh->bar_count.fetch_add(1) == c->nranks - 1) {
         c->sh->bar_count.store(0);
         c->sh->bar_gen.fetch_add(1);
     } else {
-        while (c->sh->bar_gen.load() == gen) sched_yield();
+        while (c->sh->bar_gen.load() == gen) {
+            if (c->sh->aborted.load()) return false;
+            sched_yield();
+        }
     }
+    return !c->sh->aborted.load();
 }
 size_t tsize(ncclDataType_t t) { return (t == ncclFloat64 || t == ncclInt64 || t == ncclUint64) ? 8 : 4; }
 } // namespace
@@ -87,7 +95,11 @@ ncclResult_t ncclCommDestroy(ncclComm_t comm)
     delete c;
     return ncclSuccess;
 }
-ncclResult_t ncclCommAbort(ncclComm_t comm) { return ncclCommDestroy(comm); }
+ncclResult_t ncclCommAbort(ncclComm_t comm)
+{
+    ((Comm *)comm)->sh->aborted.store(1); // releases every peer spinning in a barrier, Send or Recv -- with an error
+    return ncclCommDestroy(comm);
+}
 
 ncclResult_t ncclAllReduce(const void *sendbuff, void *recvbuff, size_t count, ncclDataType_t dt, ncclRedOp_t op,
                            ncclComm_t comm, hipStream_t stream)
@@ -97,7 +109,7 @@ ncclResult_t ncclAllReduce(const void *sendbuff, void *recvbuff, size_t count, n
     if (hipStreamSynchronize(stream) != hipSuccess) return ncclUnhandledCudaError;
     size_t nb = count * tsize(dt);
     if (hipMemcpy(c->sh->ar[c->rank], sendbuff, nb, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
-    barrier(c);
+    if (!barrier(c)) return ncclRemoteError;
     char out[64 * 8];
     if (dt == ncclFloat64 && op == ncclSum) {
         double *o = (double *)out;
@@ -116,7 +128,7 @@ ncclResult_t ncclAllReduce(const void *sendbuff, void *recvbuff, size_t count, n
     } else {
         return ncclInvalidArgument;
     }
-    barrier(c);
+    if (!barrier(c)) return ncclRemoteError;
     if (hipMemcpy(recvbuff, out, nb, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
     return ncclSuccess;
 }
@@ -128,7 +140,11 @@ ncclResult_t ncclSend(const void *sendbuff, size_t count, ncclDataType_t dt, int
     if (nb > CAP) return ncclInvalidArgument;
     if (hipStreamSynchronize(stream) != hipSuccess) return ncclUnhandledCudaError;
     Box &b = c->sh->box[c->rank][peer];
-    while (b.head.load() - b.tail.load() >= (uint64_t)SLOTS) sched_yield();
+    while (b.head.load() - b.tail.load() >= (uint64_t)SLOTS) {
+        if (c->sh->aborted.load()) return ncclRemoteError;
+        sched_yield();
+    }
+    if (c->sh->aborted.load()) return ncclRemoteError;
     int s = (int)(b.head.load() % SLOTS);
     if (hipMemcpy(b.data[s], sendbuff, nb, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
     b.bytes[s] = nb;
@@ -142,7 +158,10 @@ ncclResult_t ncclRecv(void *recvbuff, size_t count, ncclDataType_t dt, int peer,
     size_t nb = count * tsize(dt);
     (void)stream;
     Box &b = c->sh->box[peer][c->rank];
-    while (b.head.load() == b.tail.load()) sched_yield();
+    while (b.head.load() == b.tail.load()) {
+        if (c->sh->aborted.load()) return ncclRemoteError;
+        sched_yield();
+    }
     int s = (int)(b.tail.load() % SLOTS);
     if (b.bytes[s] != nb) {
         fprintf(stderr, "[nccl_shim] rank %d: message from %d has %zu bytes, receive expects %zu\n", c->rank, peer, b.bytes[s], nb);

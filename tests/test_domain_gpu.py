@@ -109,6 +109,46 @@ def test_slab_decomposition_matches_single_gpu(nproc, nvt, stage, mode):
         assert counts and max(counts) > 0, "no interior tiles: the overlapped window was not exercised"
 
 
+@pytest.mark.parametrize("nproc,nvt", [(2, 1), (3, 0)])
+def test_violation_inside_a_fused_slab_window(nproc, nvt):
+    """An over-confident window plan (safety factor 1.6 on the validity radii): particles leave the rows' validity
+    INSIDE the fused multi-rank windows, the flag travels with the per-step all-reduce, every rank skips the rest of the
+    window, the state falls back to the last complete step and the run resumes there -- and still reproduces the
+    single-handle trajectory.  The worker requires violations >= 1 and the fused window form in every window."""
+    env = {"DOM_KT": "2.0", "DOM_STEPS": "120", "DOM_NVT": str(nvt), "MDHIP_DOM_STAGE": "device", "DOM_ASYNC": "native",
+           "MDHIP_RCCL_PATH": _build_shim(), "DOM_PRUNE": "1", "DOM_POLY": "0", "DOM_ELONG": "0", "DOM_N": "8000",
+           "DOM_BACKEND": "gloo", "DOM_SAFETY": "1.6", "DOM_EXPECT_VIOL": "1"}
+    _launch(nproc, env, 29931 + nproc)
+
+
+def test_a_failing_rank_releases_its_peer():
+    """MDHIP_DOM_FAIL=1:7 -- rank 1 throws inside its third-or-so window at step 7.  Its DomAbortGuard aborts the
+    communicator; rank 0, blocked in (or arriving at) the step's collective, must come back with an error promptly
+    instead of waiting for the watchdog.  Both ranks exit non-zero; the job ends well inside the watchdog's 240 s."""
+    import time
+    env = dict(os.environ)
+    env.update({"DOM_KT": "2.0", "DOM_STEPS": "60", "DOM_NVT": "1", "MDHIP_DOM_STAGE": "device", "DOM_ASYNC": "native",
+                "MDHIP_RCCL_PATH": _build_shim(), "DOM_PRUNE": "1", "DOM_N": "8000", "DOM_BACKEND": "gloo",
+                "MDHIP_DOM_FAIL": "1:2", "OMP_NUM_THREADS": "2", "DOM_WATCHDOG": "240"})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29957", os.path.join(ROOT, "tests", "domain_gpu_worker.py")]
+    t0 = time.time()
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        out, err = p.communicate(timeout=200)
+    except subprocess.TimeoutExpired:
+        os.killpg(p.pid, signal.SIGKILL)
+        p.communicate()
+        raise AssertionError("a rank kept waiting for its failed peer")
+    took = time.time() - t0
+    sys.stderr.write(err[-2500:])
+    assert p.returncode != 0
+    assert "injected failure" in err, "rank 1 did not fail where asked"
+    # the peer's error names the collective that came back with an error (not a watchdog dump)
+    assert "nccl" in err.lower() and "Timeout" not in err and "dump_traceback" not in err
+    assert took < 150
+
+
 def test_slab_half_million_particles_per_rank():
     """BASELINE configs[3]'s per-rank load (4,194,304 / 8 = 524,288 owned particles per GPU): two ranks, the
     2^20-particle cube of the metric cut into two slabs of 52.7 (as bench.py --gpus 2 --scaling strong does), native

@@ -299,3 +299,20 @@ def test_inner_halo_switch_changes_nothing_but_the_staging(oracle, monkeypatch):
     ref = oracle.run(s["x"], s["img"], s["v"], s["f"], s["diam"], s["box"], 2.5, oracle.make_pot(0, LJ), dt, nsteps, ensemble=1,
                      tau=0.1, ktemp=kt, r1=r1, r2=r2, nthreads=8)
     assert np.array_equal(i1, ref["img"]) and np.abs(x1 - ref["x"]).max() <= 1e-8
+
+
+def test_lj_cutoff_must_be_positive_and_finite():
+    """md_set_potential turns the LJ kinds' r_cut into a threshold on d^2 (the smallest double whose square root reaches
+    r_cut): zero, negative and non-finite cutoffs are refused with an error instead of searching for that threshold."""
+    from moleculardynamics.jl_amd import MDDevice, MdhipError
+    s = lj_system(512)
+    with MDDevice(3, s["n"], s["box"], 2.5) as d:
+        for bad in (0.0, -2.5, float("inf"), float("nan")):
+            with pytest.raises(MdhipError, match="r_cut"):
+                d.set_potential(0, [1.0, 1.0, bad])
+            with pytest.raises(MdhipError, match="r_cut"):
+                d.set_potential(3, [1.0, 1.0, bad, 0.0, 2.0])
+        d.set_potential(0, [1.0, 1.0, 2.5])          # the handle is still usable
+        d.upload(s["x"], s["v"], s["f"], s["img"], s["diam"])
+        u, w = d.compute_forces()
+        assert np.isfinite(u) and np.isfinite(w)
