@@ -129,6 +129,14 @@ int md_fire_minimize(md_ctx *ctx, int64_t max_steps, double tol, double dt_initi
 int md_run_brownian(md_ctx *ctx, int64_t nsteps, double dt, double ktemp, uint64_t seed, int64_t first_step,
                     int64_t virial_every, double *out /* [4] */);
 
+/* Frame export at the trajectory cadence (src/simulation.jl:139-171: the dump holds positions and image counters).
+ * md_snapshot_begin gathers both in original-particle order (positions wrapped exactly as md_download wraps them) and
+ * starts the device-to-host copy into pinned memory on a copy stream of the library; it does NOT wait.  The caller may
+ * enqueue the next segment (md_run ...) at once: the copy overlaps it.  md_snapshot_end waits for the copy and fills the
+ * caller's d x N column-major arrays (either may be NULL).  One frame in flight per handle. */
+int md_snapshot_begin(md_ctx *ctx);
+int md_snapshot_end(md_ctx *ctx, double *x, int32_t *images);
+
 /* compute_kinetic: src/thermostat.jl:50-60 */
 int md_kinetic(md_ctx *ctx, double *kinetic);
 

@@ -252,6 +252,19 @@ function download(dev::Device)
     return X, V, F, IM
 end
 
+"start the asynchronous export of one frame (positions + images); collect it with `snapshot_end` after the next segment"
+function snapshot_begin(dev::Device)
+    check(dev, ccall((:md_snapshot_begin, LIB), Cint, (Ptr{Cvoid},), dev.h))
+    return nothing
+end
+
+function snapshot_end(dev::Device)
+    X = Matrix{Float64}(undef, dev.dim, dev.n)
+    IM = Matrix{Int32}(undef, dev.dim, dev.n)
+    check(dev, ccall((:md_snapshot_end, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Int32}), dev.h, X, IM))
+    return X, IM
+end
+
 # ---- output: src/io.jl ---------------------------------------------------------------------------------------------
 function generate_log_times(; max_iter::Int=10000, logn::Int=40, logbase::Float64=1.35)   # src/io.jl:17-36
     dtime = Int[]
@@ -359,6 +372,17 @@ function run_simulation!(state::SimulationState, params::Parameters, ensemble::E
     snap_i = 1
     step = 0
     uwk = zeros(3); bout = zeros(4)
+    # A frame is exported asynchronously (snapshot_begin) and collected after the NEXT segment has run: its device-to-host
+    # copy overlaps that segment.  `pending` = the files the frame in flight goes to: (path, step, mode).
+    pending = Tuple{String,Int,String}[]
+    function collect_frame!()
+        isempty(pending) && return
+        X, IM = snapshot_end(dev)
+        for (path, at, mode) in pending
+            write_to_file_lammps(path, at, state.unitcell, n, X, IM, state.diameters, d; mode=mode)
+        end
+        empty!(pending)
+    end
     while step < total_steps
         next_out = mod(step, frequency) == 0 ? step : (step ÷ frequency + 1) * frequency
         if log_times
@@ -388,8 +412,8 @@ function run_simulation!(state::SimulationState, params::Parameters, ensemble::E
                               r2::Ptr{Float64}, uwk::Ptr{Float64})::Cint
             check(dev, rc)
         end
+        collect_frame!()                 # the frame exported before this segment
         step = last + 1
-        frame = nothing
         if mod(last, frequency) == 0                                               # src/simulation.jl:118-136
             if brownian
                 T = ensemble.ktemp                                                 # src/simulation.jl:259-266
@@ -403,16 +427,15 @@ function run_simulation!(state::SimulationState, params::Parameters, ensemble::E
             end
             open(io -> @printf(io, "%d %.6f %.6f %.6f\n", last, e, T, P), thermo_file, "a")
             state.system.energy_and_forces.energy = uwk[1]; state.system.energy_and_forces.virial = uwk[2]
-            frame = download(dev)                                                  # src/simulation.jl:139-151
-            write_to_file_lammps(trajectory_file, last, state.unitcell, n, frame[1], frame[4], state.diameters, d; mode="a")
+            push!(pending, (trajectory_file, last, "a"))                           # src/simulation.jl:139-151
         end
         if log_times && snap_i <= length(snapshot_times) && snapshot_times[snap_i] == last   # :153-171
-            frame === nothing && (frame = download(dev))
-            write_to_file_lammps(joinpath(pathname, "snapshot.$(last)"), last, state.unitcell, n, frame[1], frame[4],
-                                 state.diameters, d; mode="w")
+            push!(pending, (joinpath(pathname, "snapshot.$(last)"), last, "w"))
             snap_i += 1
         end
+        isempty(pending) || snapshot_begin(dev)      # gather + copy to pinned memory: overlaps the next segment
     end
+    collect_frame!()
     X, V, F, IM = download(dev)
     unpack!(state.system.positions, X); unpack!(state.system.energy_and_forces.forces, F)
     brownian || (state.velocities = [V[:, i] for i in 1:n])

@@ -16,7 +16,7 @@ MD_NVE, MD_NVT = 0, 1
 EXPORTS = [
     "md_create", "md_destroy", "md_last_error", "md_set_potential", "md_set_potential_source", "md_set_skin",
     "md_set_inner_skin",
-    "md_upload", "md_download", "md_compute_forces", "md_neighbor_pairs", "md_run", "md_kinetic",
+    "md_upload", "md_download", "md_snapshot_begin", "md_snapshot_end", "md_compute_forces", "md_neighbor_pairs", "md_run", "md_kinetic",
     "md_scale_velocities", "md_profile", "md_get_stats", "md_version", "md_fire_minimize", "md_run_brownian",
     "md_create_domain", "md_dom_set_uniform", "md_dom_upload", "md_dom_download", "md_dom_migrate_pack",
     "md_dom_migrate_unpack", "md_dom_halo_pack", "md_dom_halo_unpack", "md_dom_build", "md_dom_get_sendbuf",
@@ -72,6 +72,10 @@ def load():
     L.md_upload.restype = C.c_int
     L.md_download.argtypes = [vp, dp, dp, dp, ip]
     L.md_download.restype = C.c_int
+    L.md_snapshot_begin.argtypes = [vp]
+    L.md_snapshot_begin.restype = C.c_int
+    L.md_snapshot_end.argtypes = [vp, dp, ip]
+    L.md_snapshot_end.restype = C.c_int
     L.md_compute_forces.argtypes = [vp, dp, dp]
     L.md_compute_forces.restype = C.c_int
     L.md_neighbor_pairs.argtypes = [vp, ip, C.c_int64, C.POINTER(C.c_int64)]

@@ -2051,8 +2051,8 @@ __global__ void __launch_bounds__(MD_BLOCK)
         }
         xo[o + c] = xc;
         io[o + c] = im;
-        vo[o + c] = s.v[c][k];
-        fo[o + c] = s.f[c][k];
+        if (vo) vo[o + c] = s.v[c][k]; // (md_snapshot_begin: positions and images only)
+        if (fo) fo[o + c] = s.f[c][k];
     }
 }
 

@@ -178,6 +178,16 @@ struct md_ctx {
 
     DBuf<double> io_x, io_v, io_f, io_d;
     DBuf<int32_t> io_i;
+    // asynchronous frame export (md_snapshot_begin / md_snapshot_end): device staging of its own, pinned host buffers,
+    // a copy stream, and the event the host waits on
+    DBuf<double> snap_x;
+    DBuf<int32_t> snap_i;
+    double *pin_x = nullptr;
+    int32_t *pin_i = nullptr;
+    size_t pin_n = 0;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_snap_ready = nullptr, ev_snap_copied = nullptr;
+    bool snap_pending = false;
 
     bool list_valid = false;
     int64_t steps_since_build = 0;
@@ -1362,6 +1372,11 @@ int md_destroy(md_ctx *ctx)
     if (ctx->stream) {
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipStreamDestroy(ctx->own_stream);
+        if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+        if (ctx->ev_snap_ready) (void)hipEventDestroy(ctx->ev_snap_ready);
+        if (ctx->ev_snap_copied) (void)hipEventDestroy(ctx->ev_snap_copied);
+        if (ctx->pin_x) (void)hipHostFree(ctx->pin_x);
+        if (ctx->pin_i) (void)hipHostFree(ctx->pin_i);
     }
     delete ctx->rtc;
     ctx->rtc = nullptr;
@@ -1541,6 +1556,61 @@ int md_download(md_ctx *ctx, double *x, double *v, double *f, int32_t *images)
     if (f) HIPCHK(hipMemcpyAsync(f, ctx->io_f.p, nd * sizeof(double), hipMemcpyDeviceToHost, st));
     if (images) HIPCHK(hipMemcpyAsync(images, ctx->io_i.p, nd * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    API_END
+}
+
+// Frame export at the trajectory cadence (src/simulation.jl:139-171 writes positions + images): the gather runs on the
+// handle's stream, the device-to-host copy on a copy stream into pinned memory, and nobody waits -- the caller enqueues the
+// next segment (md_run) and collects the frame with md_snapshot_end when it wants to write it.
+int md_snapshot_begin(md_ctx *ctx)
+{
+    API_BEGIN
+    require_state(ctx, "md_snapshot_begin");
+    if (ctx->snap_pending) throw HipError("md_snapshot_begin: the previous frame has not been collected (md_snapshot_end)");
+    size_t nd = (size_t)ctx->n * ctx->dim;
+    hipStream_t st = ctx->stream;
+    if (!ctx->copy_stream) {
+        HIPCHK(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&ctx->ev_snap_ready, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&ctx->ev_snap_copied, hipEventDisableTiming));
+    }
+    if (ctx->pin_n < nd) {
+        if (ctx->pin_x) (void)hipHostFree(ctx->pin_x);
+        if (ctx->pin_i) (void)hipHostFree(ctx->pin_i);
+        ctx->pin_x = nullptr;
+        ctx->pin_i = nullptr;
+        ctx->pin_n = 0;
+        HIPCHK(hipHostMalloc((void **)&ctx->pin_x, nd * sizeof(double), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void **)&ctx->pin_i, nd * sizeof(int32_t), hipHostMallocDefault));
+        ctx->pin_n = nd;
+    }
+    ctx->snap_x.ensure(nd);
+    ctx->snap_i.ensure(nd);
+    DevState s = ctx->dev(ctx->cur);
+    int nb = ctx->nblk;
+    if (ctx->dim == 3)
+        k_export<3><<<nb, MD_BLOCK, 0, st>>>((int)ctx->n, s, ctx->grid, ctx->snap_x.p, nullptr, nullptr, ctx->snap_i.p);
+    else
+        k_export<2><<<nb, MD_BLOCK, 0, st>>>((int)ctx->n, s, ctx->grid, ctx->snap_x.p, nullptr, nullptr, ctx->snap_i.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(ctx->ev_snap_ready, st));
+    HIPCHK(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_snap_ready, 0));
+    HIPCHK(hipMemcpyAsync(ctx->pin_x, ctx->snap_x.p, nd * sizeof(double), hipMemcpyDeviceToHost, ctx->copy_stream));
+    HIPCHK(hipMemcpyAsync(ctx->pin_i, ctx->snap_i.p, nd * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->copy_stream));
+    HIPCHK(hipEventRecord(ctx->ev_snap_copied, ctx->copy_stream));
+    ctx->snap_pending = true;
+    API_END
+}
+
+int md_snapshot_end(md_ctx *ctx, double *x, int32_t *images)
+{
+    API_BEGIN
+    if (!ctx->snap_pending) throw HipError("md_snapshot_end: no frame in flight (md_snapshot_begin first)");
+    HIPCHK(hipEventSynchronize(ctx->ev_snap_copied));
+    ctx->snap_pending = false;
+    size_t nd = (size_t)ctx->n * ctx->dim;
+    if (x) memcpy(x, ctx->pin_x, nd * sizeof(double));
+    if (images) memcpy(images, ctx->pin_i, nd * sizeof(int32_t));
     API_END
 }
 

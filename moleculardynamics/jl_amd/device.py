@@ -102,6 +102,19 @@ class MDDevice:
         self._chk(self._L.md_download(self._h, _dp(x), _dp(v), _dp(f), _ip(im)))
         return x, v, f, im
 
+    def snapshot_begin(self):
+        """Start the export of one frame (positions + images, what the trajectory dump holds: src/simulation.jl:139-171):
+        gather on the device, copy to pinned host memory on a copy stream.  Does not wait -- run the next segment and
+        collect the frame with snapshot_end()."""
+        self._chk(self._L.md_snapshot_begin(self._h))
+
+    def snapshot_end(self):
+        shp = (self.n, self.dim)
+        x = np.empty(shp)
+        im = np.empty(shp, dtype=np.int32)
+        self._chk(self._L.md_snapshot_end(self._h, _dp(x), _ip(im)))
+        return x, im
+
     # -- compute --------------------------------------------------------------------------
     def compute_forces(self):
         u, w = C.c_double(), C.c_double()

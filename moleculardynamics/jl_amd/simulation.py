@@ -78,6 +78,17 @@ def run_simulation(state, params, ensemble, total_steps, frequency, pathname, tr
     if log_times:
         snapshot_times = [0] + _io.generate_log_times()
     writer = _io.AsyncWriter()      # frames are formatted and written while the next segment runs
+    # A frame is exported asynchronously (md_snapshot_begin: gather + copy to pinned memory on a copy stream) and collected
+    # AFTER the next segment has been run: the device-to-host copy overlaps that segment, the formatting and the file
+    # write overlap the one after (writer thread).  `pending` = where the frame in flight goes.
+    pending = []
+
+    def collect():
+        if pending:
+            x, img = dev.snapshot_end()
+            for path, at, mode in pending:
+                writer.submit(_io.write_to_file_lammps, path, at, state.unitcell, n, x, img, state.diameters, dim, mode=mode)
+            pending.clear()
 
     step = 0
     while step < total_steps:
@@ -90,8 +101,9 @@ def run_simulation(state, params, ensemble, total_steps, frequency, pathname, tr
                 next_out = min(next_out, snapshot_times[snap_i])
         last = min(next_out, total_steps - 1)
         U, W, K = segment(step, last - step + 1)
+        collect()                       # the frame exported before this segment: its copy had the whole segment to finish
         step = last + 1
-        frame = None
+        want_frame = False
         if last % frequency == 0:
             if brownian:
                 temperature = ensemble.ktemp                            # src/simulation.jl:259-266
@@ -108,15 +120,16 @@ def run_simulation(state, params, ensemble, total_steps, frequency, pathname, tr
             state.system.energy_and_forces.energy = U
             state.system.energy_and_forces.virial = W
             if write_trajectory:
-                x, _, _, img = frame = dev.download()
-                writer.submit(_io.write_to_file_lammps, trajectory_file, last, state.unitcell, n, x, img,
-                              state.diameters, dim, mode="a")
+                pending.append((trajectory_file, last, "a"))
+                want_frame = True
         if snapshot_times is not None and snap_i < len(snapshot_times) and snapshot_times[snap_i] == last:
-            x, _, _, img = frame if frame is not None else dev.download()
-            writer.submit(_io.write_to_file_lammps, os.path.join(pathname, f"snapshot.{last}"), last, state.unitcell,
-                          n, x, img, state.diameters, dim, mode="w")
+            pending.append((os.path.join(pathname, f"snapshot.{last}"), last, "w"))
+            want_frame = True
             snap_i += 1
+        if want_frame:
+            dev.snapshot_begin()
 
+    collect()
     writer.close()
     x, v, f, img = dev.download()
     state.system.positions = x

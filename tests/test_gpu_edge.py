@@ -305,6 +305,7 @@ def test_lj_cutoff_must_be_positive_and_finite():
     """md_set_potential turns the LJ kinds' r_cut into a threshold on d^2 (the smallest double whose square root reaches
     r_cut): zero, negative and non-finite cutoffs are refused with an error instead of searching for that threshold."""
     from moleculardynamics.jl_amd import MDDevice, MdhipError
+    from tests.util import lj_system
     s = lj_system(512)
     with MDDevice(3, s["n"], s["box"], 2.5) as d:
         for bad in (0.0, -2.5, float("inf"), float("nan")):
@@ -316,3 +317,27 @@ def test_lj_cutoff_must_be_positive_and_finite():
         d.upload(s["x"], s["v"], s["f"], s["img"], s["diam"])
         u, w = d.compute_forces()
         assert np.isfinite(u) and np.isfinite(w)
+
+
+def test_snapshot_export_overlaps_the_next_segment():
+    """md_snapshot_begin / md_snapshot_end (async staging of the trajectory frames): the frame
+    collected AFTER another segment has run is the state at the time of snapshot_begin -- positions and images exactly as
+    md_download gave them then -- and a second frame cannot be started while one is in flight."""
+    from moleculardynamics.jl_amd import MDDevice, MdhipError
+    from tests.util import lj_system
+    s = lj_system(32768, kT=1.5)
+    with MDDevice(3, s["n"], s["box"], 2.5) as d:
+        d.set_potential(0, LJ)
+        d.upload(s["x"], s["v"], s["f"], s["img"], s["diam"])
+        d.run(30, 0.002, thermo=False)
+        x0, _, _, i0 = d.download()
+        d.snapshot_begin()
+        with pytest.raises(MdhipError, match="not been collected"):
+            d.snapshot_begin()
+        d.run(40, 0.002, thermo=False)          # list builds and prunes happen in here: the frame must not move
+        xs, is_ = d.snapshot_end()
+        assert np.array_equal(xs, x0) and np.array_equal(is_, i0)
+        x1, _, _, _ = d.download()
+        assert not np.array_equal(x1, x0)
+        with pytest.raises(MdhipError, match="no frame in flight"):
+            d.snapshot_end()
