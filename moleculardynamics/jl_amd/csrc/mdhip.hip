@@ -1253,7 +1253,16 @@ static int create_common(int dim, int64_t n_global, int64_t n_cap, bool domain, 
         if (device_id >= ndev) throw HipError("md_create: device_id out of range");
         ctx->device = device_id;
         HIPCHK(hipSetDevice(device_id));
-        HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        if (domain) {
+            // a slab handle's stream carries the collectives and the boundary tiles: the HIGHEST priority, so that the
+            // record exchange is not starved of CUs by the interior tiles running beside it on the (lowest-priority)
+            // interior stream -- round 2 saw RCCL's copy kernel stretched from 15 to 84 us there
+            int plo = 0, phi = 0;
+            HIPCHK(hipDeviceGetStreamPriorityRange(&plo, &phi));
+            HIPCHK(hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, phi));
+        } else {
+            HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        }
         ctx->own_stream = ctx->stream;
         ctx->dim = dim;
         ctx->n_global = n_global;
