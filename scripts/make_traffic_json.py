@@ -22,7 +22,10 @@ out = {
     "read_bytes_corrected_x2": 2 * fetch * 1024 if fetch else None,
     "traffic_bytes_raw": (fetch + write) * 1024 if fetch and write else None,
     "traffic_bytes_corrected": (2 * fetch + write) * 1024 if fetch and write else None,
-    "algorithmic_bytes": 380.0 * 1048576,
+    "algorithmic_bytes": (380.0 - 32.0) * 1048576,   # the kernel's share: SURVEY.md 8(d)'s NVT figure minus the cell binning
+    "algorithmic_bytes_whole_step": 380.0 * 1048576,
+    "note": "the x2 read correction is the guide's for 16-B-per-lane streaming reads (the record gathers); the rows are read "
+            "8 B per lane, where it is uncalibrated: corrected = upper bound, raw = lower bound of the bytes that left L2",
     "kernel_sources_sha256_16": bench.kernel_hash(),
     "recipe": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes of `python bench.py --steps 20 --warmup 5 --equil 60` (scripts/profile_round.sh)",
 }

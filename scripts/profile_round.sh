@@ -14,6 +14,13 @@ python bench.py --gpus 1 --config 4 --steps 100 --warmup 20 --no-cpu-baseline > 
 echo "bench config4 done"
 MDHIP_BENCH_DOMAIN=1 python bench.py --steps 200 --warmup 50 --no-cpu-baseline > $O/bench_slab_path_world1_rccl.json 2> $O/bench_slab.err || echo "slab path bench failed"
 echo "bench slab done"
+# energies every step (the reference's frequency = 1): one md_run call per step, the last step of each with U and W
+python bench.py --steps 200 --warmup 50 --frequency 1 --no-cpu-baseline > $O/bench_n1_frequency1.json 2> $O/bench_f1.err
+echo "bench frequency 1 done"
+# bench.py --gpus 2 launches its two ranks itself (both on this box's one GPU: gloo carries the exchanges) -- the
+# launcher's plumbing, not a scaling number
+MDHIP_BENCH_BACKEND=gloo python3 bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_gpus2_launcher_gloo_one_gpu.json 2> $O/bench_g2.err || echo "2-rank launcher run failed"
+echo "bench --gpus 2 done"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks -- python3 $R/bench.py --no-cpu-baseline --steps 400 --warmup 50 > $O/ks.log 2>&1
 cp $(ls $O/ks/*/*kernel_stats.csv | head -1) $O/kernel_stats.csv
