@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
 """bench.py -- particle-steps/s of the device-resident MD step loop on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--config 3|4] [--scaling weak|strong]
+    python bench.py --gpus N --steps K --warmup W [--config 3|4] [--scaling weak|strong] [--frequency k]
 
 A "step" is one full velocity-Verlet step (first half-kick + drift, pair forces, second half-kick, thermostat)
-of every particle.
+of every particle.  --gpus N > 1 with no WORLD_SIZE in the environment: the script starts its N ranks itself (one
+process per GPU, the torch.distributed.run environment) and relays rank 0's JSON line; under a launcher that set
+WORLD_SIZE, N has to be that world size.
 
   --config 3 (default)  BASELINE.json configs[2], the configuration the metric is quoted on: 1,048,576 monodisperse
                         Lennard-Jones particles, rho = 0.897, r_cut = list cutoff = 2.5, dt = 0.001, NVT (Bussi
