@@ -370,42 +370,22 @@ __global__ void __launch_bounds__(MD_BT_THREADS)
         cntB[pt] = cnt;
     __syncthreads();
     MD_STAMP(5);
-    // 4. compact the referenced particles into the halo.  The tile's OWN particles come first, in lane order (record t of
-    // the image is the particle of lane t, referenced or not; lanes beyond n: a far-away filler), the others behind them
-    // by unique cell (staged order: cell by cell, particles of a cell in slot order).  An own record's offset in the image is
-    // then also the offset of that particle's force accumulator (k_step_tile's third-law section).
+    // 4. compact the referenced particles into the halo
     int H;
     {
+        // by unique cell (halo order = staged order: cell by cell, particles of a cell in slot order)
         const int per = (MD_NCMAX + MD_BT_THREADS - 1) / MD_BT_THREADS;
-        const int own0 = tile * MD_TILE, own1 = min(n, own0 + MD_TILE);
-        // (a cell's staged particles are the global slots src0 .. src0 + count: the own ones are one bit range of its mask)
-        auto own_mask = [&](int u) -> unsigned long long {
-            const int src0 = cell_start[ucell[u]];
-            int lo = max(own0 - src0, 0), hi = min(own1 - src0, (int)ccnt[u]);
-            if (hi <= lo) return 0ull;
-            unsigned long long m = (hi >= 64) ? ~0ull : ((1ull << hi) - 1ull);
-            return m & ~((1ull << lo) - 1ull);
-        };
         int c = 0;
         for (int q = 0; q < per; ++q) {
             int u = tid * per + q;
-            if (u < nu) c += __popcll(refmask[u] & ~own_mask(u));
+            if (u < nu) c += __popcll(refmask[u]);
         }
-        int Hother;
-        int run = MD_TILE + block_excl_scan(c, sh_scan, &Hother);
-        H = MD_TILE + Hother;
+        int run = block_excl_scan(c, sh_scan, &H);
         for (int q = 0; q < per; ++q) {
             int u = tid * per + q;
             if (u >= nu) continue;
-            const unsigned long long om = own_mask(u);
+            unsigned long long mk = refmask[u];
             const int base = coff[u], src0 = cell_start[ucell[u]];
-            unsigned long long mk = om;
-            while (mk) { // own particles: the lane number
-                int bit = __ffsll((long long)mk) - 1;
-                mk &= mk - 1ull;
-                newidx[base + bit] = (uint16_t)(src0 + bit - own0);
-            }
-            mk = refmask[u] & ~om;
             while (mk) {
                 int bit = __ffsll((long long)mk) - 1;
                 mk &= mk - 1ull;
@@ -414,7 +394,6 @@ __global__ void __launch_bounds__(MD_BT_THREADS)
                 ++run;
             }
         }
-        if (tid < MD_TILE) halo[(size_t)tile * hcap + tid] = (own0 + tid < own1) ? (uint32_t)(own0 + tid) : 0xffffffffu;
         if (tid == 0) {
             halo_count[tile] = H;
             atomicMax(&sc->hmax, H);

@@ -605,7 +605,7 @@ __global__ void __launch_bounds__(MD_BLOCK)
     int H = halo_count[blockIdx.x];
     for (int h = threadIdx.x; h < H; h += blockDim.x) {
         uint32_t e = hl[h];
-        if (e != 0xffffffffu && e >= (uint32_t)n) hl[h] = (uint32_t)gowner[e - n] | (gcode[e - n] << 26); // (0xffffffff: a filler record)
+        if (e >= (uint32_t)n) hl[h] = (uint32_t)gowner[e - n] | (gcode[e - n] << 26);
     }
 }
 
