@@ -43,8 +43,14 @@ enum { MD_NVE = 0, MD_NVT = 1 };
 
 /* Replaces CellListMap.ParticleSystem(xpositions, unitcell, cutoff, ...) +
  * SimulationState's device-side half: src/initialization.jl:100-107, src/types.jl:15-32.
- * box is the d x d unit cell (column-major); only diagonal (orthorhombic) cells are
- * accepted in this version.  list_cutoff is CellListMap's cutoff (independent
+ * box is the d x d unit cell, column-major, COLUMNS = lattice vectors (Julia's Matrix as
+ * src/initialization.jl:7-18 builds it).  A diagonal matrix is an orthorhombic cell (the fast
+ * paths); any other non-singular matrix is a general (triclinic) cell: positions wrap as
+ * wrap_to_box does (src/boundary.jl:7-17: frac = U^-1 x, image += floor.(frac),
+ * x = U (frac - floor.(frac))), periodic images are lattice-vector translations, and the linked
+ * cells are cut in fractional coordinates -- every pair of opposite cell faces must be at least
+ * 3 list radii apart (md_create / md_set_skin fail otherwise).  General cells are single-handle:
+ * md_create_domain refuses them.  list_cutoff is CellListMap's cutoff (independent
  * of the potential's own r_cut).  device_id < 0 means "current device".               */
 int md_create(int dim, int64_t n_particles, const double *box, double list_cutoff, int device_id, md_ctx **out);
 int md_destroy(md_ctx *ctx);

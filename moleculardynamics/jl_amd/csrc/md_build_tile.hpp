@@ -197,9 +197,10 @@ __global__ void __launch_bounds__(MD_BT_THREADS)
     const double4 org = P[tile * MD_TILE]; // tile-local frame: keeps fp32 coordinates small
     double4 pd = P[active ? k : n - 1];
     const float xi = (float)(pd.x - org.x), yi = (float)(pd.y - org.y), zi = (D == 3) ? (float)(pd.z - org.z) : 0.f;
-    int ec[3] = {0, 0, 0};
+    int ec[3];
+    cell_coords<D>(pd, g, ec);
 #pragma unroll
-    for (int c = 0; c < D; ++c) ec[c] = cell_coord<D>(pos_get(pd, c), c, g) + 1;
+    for (int c = 0; c < D; ++c) ec[c] += 1;
     const int mycell = ext_linear(ec, g);
     if (tid == 0) sh_misc[0] = mycell; // first particle's cell
     const int last_active = min(n - 1, tile * MD_TILE + MD_TILE - 1) - tile * MD_TILE;

@@ -41,6 +41,8 @@ struct DevState {
     double *x0[3]; // n: positions at the last list build
     double *x1[3]; // n: positions at the last prune of the rows (== x0 when pruning is off)
     double boxL[3]; // global box lengths (periodic translation of virtual ghosts in the tiled force kernel)
+    int tric;       // 1: general (triclinic) unit cell -- translations are combinations of the lattice vectors
+    double cellA[9]; // row-major 3 x 3, COLUMNS = lattice vectors (src/boundary.jl:7-17: x = U * frac)
 };
 
 struct BoxGrid {
@@ -55,6 +57,11 @@ struct BoxGrid {
     int nb[3];  // particles (hence a 256-particle tile) form a compact block, not a stick
     int n_int_cells; // size of the (padded) interior brick-major range; ghost cells follow
     int id_bits, cell_bits;
+    // general (triclinic) unit cell, src/boundary.jl:7-17 and src/initialization.jl:7-18: A = U (row-major, columns =
+    // lattice vectors), Ainv = U^-1.  Cells live in FRACTIONAL coordinates then (cell c of particle x: floor(frac_c * nc[c])),
+    // every cell at least the list radius wide between its faces.  tric == 0: the diagonal fast paths above.
+    int tric;
+    double A[9], Ainv[9];
 };
 
 struct PotParams {
@@ -132,6 +139,79 @@ __device__ __forceinline__ double d2_ref(double dx, double dy, double dz)
         r = r + c;
     }
     return r;
+}
+
+// ---- general unit cell (reference: wrap_to_box src/boundary.jl:7-17; restated in oracle/md_oracle.c wrap_tric / tric_d2) ----
+// Fractional coordinates frac = U^-1 x, row times vector, left to right, every operation rounded (no fma).
+template <int D>
+__device__ __forceinline__ void frac_of(double x, double y, double z, const double *Ainv, double *fr)
+{
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        if (r < D) {
+            double a = Ainv[r * 3 + 0] * x + Ainv[r * 3 + 1] * y;
+            if constexpr (D == 3) a = a + Ainv[r * 3 + 2] * z;
+            fr[r] = a;
+        } else {
+            fr[r] = 0.0;
+        }
+    }
+}
+// The lazily applied wrap of a general cell: when some fractional coordinate is outside [0, 1), n = floor.(frac) is
+// returned in dn and (x, y, z) becomes U (frac - n); else nothing changes and false is returned.
+template <int D>
+__device__ __forceinline__ bool wrap_general(double &x, double &y, double &z, const double *A, const double *Ainv, int32_t *dn)
+{
+#pragma clang fp contract(off)
+    double fr[3];
+    frac_of<D>(x, y, z, Ainv, fr);
+    bool out = false;
+#pragma unroll
+    for (int r = 0; r < D; ++r) out = out || fr[r] < 0.0 || fr[r] >= 1.0;
+    dn[0] = dn[1] = dn[2] = 0;
+    if (!out) return false;
+    double fm[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int r = 0; r < D; ++r) {
+        double nn = floor(fr[r]);
+        fm[r] = fr[r] - nn;
+        dn[r] = (int32_t)nn;
+    }
+    double o[3] = {x, y, z};
+#pragma unroll
+    for (int r = 0; r < D; ++r) {
+        double a = A[r * 3 + 0] * fm[0] + A[r * 3 + 1] * fm[1];
+        if constexpr (D == 3) a = a + A[r * 3 + 2] * fm[2];
+        o[r] = a;
+    }
+    x = o[0];
+    y = o[1];
+    if constexpr (D == 3) z = o[2];
+    return true;
+}
+// Periodic translation of a (virtual) ghost by its 6-bit shift code (2 bits per lattice direction: 1 = +, 2 = -).
+// Diagonal cell: x + s L per component, one rounding.  General cell: t_r = (s0 A[r][0] + s1 A[r][1]) + s2 A[r][2] (products
+// exact, sums left to right), x_r + t_r -- the oracle's tric_d2.
+__device__ __forceinline__ void shift_xyz(double &x, double &y, double &z, uint32_t code, const double *L, int tric, const double *A)
+{
+    const uint32_t sx = code & 3u, sy = (code >> 2) & 3u, sz = (code >> 4) & 3u;
+    if (!tric) {
+        if (sx == 1u) x = x + L[0];
+        if (sx == 2u) x = x - L[0];
+        if (sy == 1u) y = y + L[1];
+        if (sy == 2u) y = y - L[1];
+        if (sz == 1u) z = z + L[2];
+        if (sz == 2u) z = z - L[2];
+    } else {
+#pragma clang fp contract(off)
+        const double s0 = sx == 1u ? 1.0 : (sx == 2u ? -1.0 : 0.0);
+        const double s1 = sy == 1u ? 1.0 : (sy == 2u ? -1.0 : 0.0);
+        const double s2 = sz == 1u ? 1.0 : (sz == 2u ? -1.0 : 0.0);
+        x = x + ((s0 * A[0] + s1 * A[1]) + s2 * A[2]);
+        y = y + ((s0 * A[3] + s1 * A[4]) + s2 * A[5]);
+        z = z + ((s0 * A[6] + s1 * A[7]) + s2 * A[8]);
+    }
 }
 
 // Row entries of tile t live at rows16[wave_tile_base + row_off(r, lane)]: groups of four
@@ -246,6 +326,25 @@ __device__ __forceinline__ int cell_coord(double xc, int c, const BoxGrid &g)
     cc = cc < 0 ? 0 : cc;
     cc = cc > g.nc[c] - 1 ? g.nc[c] - 1 : cc;
     return cc;
+}
+// interior cell coordinates of a position (0 .. nc-1 per used dimension); general cell: from the fractional coordinates
+template <int D>
+__device__ __forceinline__ void cell_coords(const double4 &p, const BoxGrid &g, int *cc)
+{
+    cc[0] = cc[1] = cc[2] = 0;
+    if (!g.tric) {
+#pragma unroll
+        for (int c = 0; c < D; ++c) cc[c] = cell_coord<D>(c == 0 ? p.x : (c == 1 ? p.y : p.z), c, g);
+    } else {
+        double fr[3];
+        frac_of<D>(p.x, p.y, p.z, g.Ainv, fr);
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            int k = (int)(fr[c] * (double)g.nc[c]);
+            k = k < 0 ? 0 : k;
+            cc[c] = k > g.nc[c] - 1 ? g.nc[c] - 1 : k;
+        }
+    }
 }
 
 // Cell numbering.  Interior cells (extended coords 1..nc) are grouped into bricks -- a balanced
@@ -442,6 +541,8 @@ __device__ __forceinline__ void source_cells(const double4 &p, bool is_xh, const
         e[c] = 0;
         b[c] = 0;
     }
+    int cc3[3];
+    cell_coords<D>(p, g, cc3); // (general cells are single-GPU only: is_xh is false there)
 #pragma unroll
     for (int c = 0; c < D; ++c) {
         double xc = pos_get(p, c);
@@ -450,7 +551,7 @@ __device__ __forceinline__ void source_cells(const double4 &p, bool is_xh, const
             e[c] = (xc < g.lo[c]) ? 0 : g.nc[c] + 1;
             continue;
         }
-        int cc = cell_coord<D>(xc, c, g);
+        int cc = cc3[c];
         e[c] = cc + 1;
         if (g.selfimg[c]) b[c] = (cc == 0) ? 1 : ((cc == g.nc[c] - 1) ? 2 : 0);
     }
@@ -471,17 +572,26 @@ __global__ void __launch_bounds__(MD_BLOCK)
     double4 p = s.pos[i];
     if (!is_xh) {
         bool moved = false;
+        if (g.tric) {
+            int32_t dn[3];
+            moved = wrap_general<D>(p.x, p.y, p.z, g.A, g.Ainv, dn);
+            if (moved) {
 #pragma unroll
-        for (int c = 0; c < D; ++c) {
-            double xc = pos_get(p, c);
-            if (xc < 0.0 || xc >= g.L[c]) {
-                double frac = g.invL[c] * xc;
-                double nn = floor(frac);
-                double fm = frac - nn;
-                s.img[c][i] += (int32_t)nn;
-                xc = g.L[c] * fm;
-                pos_set(p, c, xc);
-                moved = true;
+                for (int c = 0; c < D; ++c) s.img[c][i] += dn[c];
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < D; ++c) {
+                double xc = pos_get(p, c);
+                if (xc < 0.0 || xc >= g.L[c]) {
+                    double frac = g.invL[c] * xc;
+                    double nn = floor(frac);
+                    double fm = frac - nn;
+                    s.img[c][i] += (int32_t)nn;
+                    xc = g.L[c] * fm;
+                    pos_set(p, c, xc);
+                    moved = true;
+                }
             }
         }
         if (moved) s.pos[i] = p;
@@ -533,14 +643,8 @@ __global__ void __launch_bounds__(MD_BLOCK)
 
 __device__ __forceinline__ double4 shifted(double4 p, uint32_t code, const BoxGrid &g)
 {
-    // x_ghost = x_owner + s*L, s in {-1,0,+1} per component (2 bits each: 1 = +L, 2 = -L)
-    uint32_t sx = code & 3u, sy = (code >> 2) & 3u, sz = (code >> 4) & 3u;
-    if (sx == 1u) p.x = p.x + g.L[0];
-    if (sx == 2u) p.x = p.x - g.L[0];
-    if (sy == 1u) p.y = p.y + g.L[1];
-    if (sy == 2u) p.y = p.y - g.L[1];
-    if (sz == 1u) p.z = p.z + g.L[2];
-    if (sz == 2u) p.z = p.z - g.L[2];
+    // x_ghost = x_owner + the code's translation (shift_xyz)
+    if (code) shift_xyz(p.x, p.y, p.z, code, g.L, g.tric, g.A);
     return p;
 }
 
@@ -641,9 +745,10 @@ __global__ void __launch_bounds__(MD_BLOCK)
     int cnt = 0;
     if (active) {
         double4 pi = P[k];
-        int ec[3] = {0, 0, 0};
+        int ec[3];
+        cell_coords<D>(pi, g, ec);
 #pragma unroll
-        for (int c = 0; c < D; ++c) ec[c] = cell_coord<D>(pos_get(pi, c), c, g) + 1;
+        for (int c = 0; c < D; ++c) ec[c] += 1;
         int z0 = (D == 3) ? -1 : 0, z1 = (D == 3) ? 1 : 0;
         for (int dz = z0; dz <= z1; ++dz)
             for (int dy = -1; dy <= 1; ++dy)
@@ -1280,15 +1385,7 @@ __global__ void __launch_bounds__(MD_TILE)
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             uint32_t code = (idx[i] != 0xffffffffu) ? (idx[i] >> 26) : 0u;
-            if (code) {
-                uint32_t sx = code & 3u, sy = (code >> 2) & 3u, sz = (code >> 4) & 3u;
-                if (sx == 1u) pr[i].x = pr[i].x + s.boxL[0];
-                if (sx == 2u) pr[i].x = pr[i].x - s.boxL[0];
-                if (sy == 1u) pr[i].y = pr[i].y + s.boxL[1];
-                if (sy == 2u) pr[i].y = pr[i].y - s.boxL[1];
-                if (sz == 1u) pr[i].z = pr[i].z + s.boxL[2];
-                if (sz == 2u) pr[i].z = pr[i].z - s.boxL[2];
-            }
+            if (code) shift_xyz(pr[i].x, pr[i].y, pr[i].z, code, s.boxL, s.tric, s.cellA);
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -1478,15 +1575,7 @@ __global__ void __launch_bounds__(MD_TILE)
             double y = __builtin_fma(adt, r2[i].x, r0[i].y);
             double z = (D == 3) ? __builtin_fma(adt, r2[i].y, r1[i].x) : 0.0;
             uint32_t code = ok ? (idx[i] >> 26) : 0u;
-            if (code) {
-                uint32_t sx = code & 3u, sy = (code >> 2) & 3u, sz = (code >> 4) & 3u;
-                if (sx == 1u) x = x + s.boxL[0];
-                if (sx == 2u) x = x - s.boxL[0];
-                if (sy == 1u) y = y + s.boxL[1];
-                if (sy == 2u) y = y - s.boxL[1];
-                if (sz == 1u) z = z + s.boxL[2];
-                if (sz == 2u) z = z - s.boxL[2];
-            }
+            if (code) shift_xyz(x, y, z, code, s.boxL, s.tric, s.cellA);
             if (!ok) {
                 x = MD_SENTINEL_POS;
                 y = MD_SENTINEL_POS;
@@ -2005,15 +2094,7 @@ __global__ void __launch_bounds__(MD_BLOCK)
         int b = s.id[j];
         if (a >= b) continue;
         double4 pj = s.pos[j];
-        if (code) {
-            uint32_t sx = code & 3u, sy = (code >> 2) & 3u, sz = (code >> 4) & 3u;
-            if (sx == 1u) pj.x = pj.x + s.boxL[0];
-            if (sx == 2u) pj.x = pj.x - s.boxL[0];
-            if (sy == 1u) pj.y = pj.y + s.boxL[1];
-            if (sy == 2u) pj.y = pj.y - s.boxL[1];
-            if (sz == 1u) pj.z = pj.z + s.boxL[2];
-            if (sz == 2u) pj.z = pj.z - s.boxL[2];
-        }
+        if (code) shift_xyz(pj.x, pj.y, pj.z, code, s.boxL, s.tric, s.cellA);
         double dx = pj.x - pk.x;
         double dy = pj.y - pk.y;
         double dz = 0.0;
@@ -2039,11 +2120,13 @@ __global__ void __launch_bounds__(MD_BLOCK)
     if (k >= n) return;
     size_t o = (size_t)s.id[k] * D;
     double4 p = s.pos[k];
+    int32_t dn[3] = {0, 0, 0};
+    if (g.tric) wrap_general<D>(p.x, p.y, p.z, g.A, g.Ainv, dn);
 #pragma unroll
     for (int c = 0; c < D; ++c) {
         double xc = pos_get(p, c);
-        int32_t im = s.img[c][k];
-        if (xc < 0.0 || xc >= g.L[c]) {
+        int32_t im = s.img[c][k] + dn[c];
+        if (!g.tric && (xc < 0.0 || xc >= g.L[c])) {
             double frac = g.invL[c] * xc;
             double nn = floor(frac);
             im += (int32_t)nn;
@@ -2066,9 +2149,17 @@ __global__ void __launch_bounds__(MD_BLOCK)
     if (k >= n) return;
     size_t o = (size_t)s.id[k] * D;
     double4 p = s.pos[k];
+    if (g.tric && xi && !ii) {
+        double4 q = p;
+        int32_t dn[3];
+        if (wrap_general<D>(q.x, q.y, q.z, g.A, g.Ainv, dn)) {
+#pragma unroll
+            for (int c = 0; c < D; ++c) s.img[c][k] += dn[c];
+        }
+    }
 #pragma unroll
     for (int c = 0; c < D; ++c) {
-        if (xi && !ii) {
+        if (!g.tric && xi && !ii) {
             // new coordinates, image counters kept ("NULL: leave that array as it is", mdhip.h): the wrap of the OLD
             // coordinate is still pending (it is applied lazily, see k_wrap_count / k_export) -- fold its crossings
             // into the counter now, or they are lost with the coordinate

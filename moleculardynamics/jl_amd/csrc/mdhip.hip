@@ -128,6 +128,13 @@ struct md_ctx {
         bool xhalo_pos_stale = false;
     } dom;
     double L[3] = {1, 1, 1};
+    // general (triclinic) unit cell: A = the cell matrix (row-major 3 x 3, columns = lattice vectors), Ainv its inverse,
+    // perp[c] = distance between the faces of lattice direction c (1 / |row c of Ainv|), volume = |det A|.
+    // tric == 0 (diagonal matrix): A = diag(L), perp = L.
+    int tric = 0;
+    double A[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, Ainv[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    double perp[3] = {1, 1, 1};
+    double volume = 1.0;
     double rc = 0.0;       // list cutoff (CellListMap's cutoff)
     double skin_req = 0.6; // requested skin.  Measured best for LJ r_c=2.5 at N=2^20: 0.6 with inner rows
                            // (inner skin 0.16), 0.4 without them
@@ -267,6 +274,8 @@ struct md_ctx {
         }
         s.id = b.id.p;
         for (int c = 0; c < 3; ++c) s.boxL[c] = c < dim ? L[c] : 0.0;
+        s.tric = tric;
+        for (int c = 0; c < 9; ++c) s.cellA[c] = A[c];
         return s;
     }
 };
@@ -328,11 +337,78 @@ void alloc_state(md_ctx *c, int which, int64_t cap)
     b.id.alloc(cap + 1);
 }
 
+// The unit cell handed to md_create: classification, inverse and face distances.  The inverse is formed exactly as the
+// oracle forms it (oracle/md_oracle.c oracle_set_cell: cofactors over the determinant, no fma), so that both sides wrap
+// with the same U^-1 -- the reference's `unitcell \\ x` (src/boundary.jl:9) solves by LU instead; the difference is a
+// rounding in the fractional coordinate, which matters only for a particle within an ulp of a face.
+struct CellGeom {
+    int tric = 0;
+    double A[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, Ainv[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    double perp[3] = {1, 1, 1};
+    double volume = 1.0;
+};
+const char *cell_geometry(int dim, const double *box, CellGeom &g)
+{
+#pragma clang fp contract(off)
+    bool diag = true;
+    for (int r = 0; r < dim; ++r)
+        for (int c = 0; c < dim; ++c) {
+            double v = box[c * dim + r];
+            if (!std::isfinite(v)) return "md_create: unit cell entries must be finite";
+            if (r != c && v != 0.0) diag = false;
+            g.A[r * 3 + c] = v;
+        }
+    if (diag) {
+        g.volume = 1.0;
+        for (int c = 0; c < dim; ++c) {
+            double v = g.A[c * 3 + c];
+            if (!(v > 0.0)) return "md_create: box lengths must be positive";
+            g.Ainv[c * 3 + c] = 1.0 / v;
+            g.perp[c] = v;
+            g.volume *= v;
+        }
+        g.tric = 0;
+        return nullptr;
+    }
+    const double *U = g.A;
+    double det;
+    if (dim == 2) {
+        det = U[0] * U[4] - U[1] * U[3];
+        if (!(std::fabs(det) > 0.0) || !std::isfinite(det)) return "md_create: the unit cell matrix is singular";
+        g.Ainv[0] = U[4] / det;
+        g.Ainv[1] = -U[1] / det;
+        g.Ainv[3] = -U[3] / det;
+        g.Ainv[4] = U[0] / det;
+    } else {
+        double c00 = U[4] * U[8] - U[5] * U[7], c01 = U[5] * U[6] - U[3] * U[8], c02 = U[3] * U[7] - U[4] * U[6];
+        det = (U[0] * c00 + U[1] * c01) + U[2] * c02;
+        if (!(std::fabs(det) > 0.0) || !std::isfinite(det)) return "md_create: the unit cell matrix is singular";
+        g.Ainv[0] = c00 / det;
+        g.Ainv[1] = (U[2] * U[7] - U[1] * U[8]) / det;
+        g.Ainv[2] = (U[1] * U[5] - U[2] * U[4]) / det;
+        g.Ainv[3] = c01 / det;
+        g.Ainv[4] = (U[0] * U[8] - U[2] * U[6]) / det;
+        g.Ainv[5] = (U[2] * U[3] - U[0] * U[5]) / det;
+        g.Ainv[6] = c02 / det;
+        g.Ainv[7] = (U[1] * U[6] - U[0] * U[7]) / det;
+        g.Ainv[8] = (U[0] * U[4] - U[1] * U[3]) / det;
+    }
+    for (int r = 0; r < dim; ++r) {
+        double n2 = 0.0;
+        for (int c = 0; c < dim; ++c) n2 += g.Ainv[r * 3 + c] * g.Ainv[r * 3 + c];
+        g.perp[r] = 1.0 / std::sqrt(n2);
+    }
+    g.volume = std::fabs(det);
+    g.tric = 1;
+    return nullptr;
+}
+
 // (re)derive the cell grid from box, cutoff and skin
 void configure_grid(md_ctx *c)
 {
     // width of this handle's region per dimension (a slab handle owns [xlo, xhi) in x)
-    double W[3] = {c->L[0], c->L[1], c->L[2]};
+    // (general cell: the distance between opposite faces -- cells are cut in fractional coordinates, md_kernels.hpp cell_coords)
+    double W[3] = {c->perp[0], c->perp[1], c->perp[2]};
     if (c->dom.on) W[0] = c->dom.xhi - c->dom.xlo;
     double lmin = 1e300;
     for (int d = 0; d < c->dim; ++d) {
@@ -344,7 +420,7 @@ void configure_grid(md_ctx *c)
     if (lmin < c->rc) {
         char b[256];
         snprintf(b, sizeof b,
-                 "box too small for the linked-cell build: need every box length >= 3*list_cutoff (slab width >= "
+                 "box too small for the linked-cell build: need every box length (general cell: face distance) >= 3*list_cutoff (slab width >= "
                  "2*list_cutoff); got limit %g for list_cutoff=%g",
                  lmin, c->rc);
         throw HipError(b);
@@ -381,6 +457,11 @@ void configure_grid(md_ctx *c)
     if (c->dom.on) {
         g.lo[0] = c->dom.xlo;
         g.selfimg[0] = 0;
+    }
+    g.tric = c->tric;
+    for (int d = 0; d < 9; ++d) {
+        g.A[d] = c->A[d];
+        g.Ainv[d] = c->Ainv[d];
     }
     // brick-major cell numbering: balanced bricks of about 2x2x3 cells (4x3 in 2-D)
     int target[3] = {2, 2, 3};
@@ -1236,13 +1317,12 @@ static int create_common(int dim, int64_t n_global, int64_t n_cap, bool domain, 
     if (!(list_cutoff > 0.0)) return fail(nullptr, "md_create: list_cutoff must be positive");
     if (domain && (nranks < 1 || rank < 0 || rank >= nranks))
         return fail(nullptr, "md_create_domain: need nranks >= 1 and 0 <= rank < nranks");
-    for (int r = 0; r < dim; ++r)
-        for (int c = 0; c < dim; ++c) {
-            double v = box[c * dim + r];
-            if (r != c && v != 0.0)
-                return fail(nullptr, "md_create: only orthorhombic (diagonal) unit cells are supported in this version");
-            if (r == c && !(v > 0.0)) return fail(nullptr, "md_create: box lengths must be positive");
-        }
+    // the unit cell: column-major d x d, columns = lattice vectors (Julia's Matrix, src/initialization.jl:7-18).  A diagonal
+    // matrix takes the orthorhombic fast paths; anything else is a general (triclinic) cell, single handle only.
+    CellGeom cg;
+    if (const char *why = cell_geometry(dim, box, cg)) return fail(nullptr, why);
+    if (cg.tric && domain)
+        return fail(nullptr, "md_create_domain: only orthorhombic (diagonal) unit cells are supported by the slab decomposition");
     md_ctx *ctx = nullptr;
     try {
         int ndev = 0;
@@ -1269,6 +1349,13 @@ static int create_common(int dim, int64_t n_global, int64_t n_cap, bool domain, 
         ctx->ncap = n_cap;
         ctx->n = domain ? 0 : n_cap;
         for (int c = 0; c < dim; ++c) ctx->L[c] = box[c * dim + c];
+        ctx->tric = cg.tric;
+        for (int c = 0; c < 9; ++c) {
+            ctx->A[c] = cg.A[c];
+            ctx->Ainv[c] = cg.Ainv[c];
+        }
+        for (int c = 0; c < 3; ++c) ctx->perp[c] = cg.perp[c];
+        ctx->volume = cg.volume;
         ctx->rc = list_cutoff;
         if (domain) {
             ctx->dom.on = true;
@@ -1319,7 +1406,7 @@ static int create_common(int dim, int64_t n_global, int64_t n_cap, bool domain, 
         ctx->nmax_tile.alloc(ctx->ntiles);
         // expected neighbours within rc+skin at this density, with headroom
         double dens = (double)n_global;
-        for (int c = 0; c < dim; ++c) dens /= ctx->L[c];
+        dens /= ctx->volume;
         double vol = (dim == 3) ? 4.18879020478639 * ctx->rl * ctx->rl * ctx->rl : 3.14159265358979 * ctx->rl * ctx->rl;
         int maxn = (int)(dens * vol * 1.35) + 24;
         ctx->maxn = (maxn + 3) & ~3;
@@ -1461,7 +1548,7 @@ int md_set_skin(md_ctx *ctx, double skin)
     configure_grid(ctx);
     if (ctx->rl > old_rl) {
         double dens = (double)ctx->n_global;
-        for (int c = 0; c < ctx->dim; ++c) dens /= ctx->L[c];
+        dens /= ctx->volume;
         double vol = (ctx->dim == 3) ? 4.18879020478639 * ctx->rl * ctx->rl * ctx->rl
                                      : 3.14159265358979 * ctx->rl * ctx->rl;
         int maxn = ((int)(dens * vol * 1.35) + 24 + 3) & ~3;

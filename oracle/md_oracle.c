@@ -204,8 +204,75 @@ double oracle_pressure_lrc(double cutoff, double density, double sigma)
 
 /* ---------------------------------------------------------------- pair geometry */
 
+/* General (triclinic) unit cell: src/boundary.jl:7-17 and src/initialization.jl:7-18 take any matrix U whose COLUMNS are
+ * the lattice vectors.  oracle_set_cell(dim, U) (row-major d x d, NULL: back to the diagonal cell of every call's L[]) switches
+ * the pair geometry and the wrap to it; only the brute-force pair loop runs on it (the linked cells of this file are
+ * orthorhombic).  Pair geometry, CellListMap's scheme restated: b's image is b translated by an integer combination of the
+ * lattice vectors, t_r = (s0 U[r][0] + s1 U[r][1]) + s2 U[r][2] with s in {-1, 0, 1}^d (every product exact, the sums rounded
+ * left to right), x_b' = x_b + t (rounded once per component); the image within the cutoff is unique while the cutoff is
+ * below half the smallest distance between opposite cell faces, and is found here by trying all 3^d. */
+static int g_tric = 0, g_tric_dim = 0;
+static double g_U[9], g_Uinv[9];
+
+void oracle_set_cell(int dim, const double *U)
+{
+    if (!U) {
+        g_tric = 0;
+        return;
+    }
+    g_tric = 1;
+    g_tric_dim = dim;
+    for (int i = 0; i < 9; ++i) g_U[i] = g_Uinv[i] = 0.0;
+    for (int r = 0; r < dim; ++r)
+        for (int c = 0; c < dim; ++c) g_U[r * 3 + c] = U[r * dim + c];
+    if (dim == 2) g_U[8] = 1.0;
+    /* inverse by cofactors (the test cells are well conditioned) */
+    const double *a = g_U;
+    double det = a[0] * (a[4] * a[8] - a[5] * a[7]) - a[1] * (a[3] * a[8] - a[5] * a[6]) + a[2] * (a[3] * a[7] - a[4] * a[6]);
+    g_Uinv[0] = (a[4] * a[8] - a[5] * a[7]) / det;
+    g_Uinv[1] = (a[2] * a[7] - a[1] * a[8]) / det;
+    g_Uinv[2] = (a[1] * a[5] - a[2] * a[4]) / det;
+    g_Uinv[3] = (a[5] * a[6] - a[3] * a[8]) / det;
+    g_Uinv[4] = (a[0] * a[8] - a[2] * a[6]) / det;
+    g_Uinv[5] = (a[2] * a[3] - a[0] * a[5]) / det;
+    g_Uinv[6] = (a[3] * a[7] - a[4] * a[6]) / det;
+    g_Uinv[7] = (a[1] * a[6] - a[0] * a[7]) / det;
+    g_Uinv[8] = (a[0] * a[4] - a[1] * a[3]) / det;
+}
+/* the inverse this file uses (libmdhip forms its own by the same cofactor formulas: mdhip.hip cell_geometry) */
+void oracle_get_cell_inverse(double *out9)
+{
+    for (int i = 0; i < 9; ++i) out9[i] = g_Uinv[i];
+}
+
+static inline double tric_d2(int dim, const double *xa, const double *xb, double *del)
+{
+    double best = 1e300;
+    const int z0 = (dim == 3) ? -1 : 0, z1 = (dim == 3) ? 1 : 0;
+    for (int s2 = z0; s2 <= z1; ++s2)
+        for (int s1 = -1; s1 <= 1; ++s1)
+            for (int s0 = -1; s0 <= 1; ++s0) {
+                double d[3] = {0.0, 0.0, 0.0};
+                for (int r = 0; r < dim; ++r) {
+                    double t = ((double)s0 * g_U[r * 3 + 0] + (double)s1 * g_U[r * 3 + 1]) + (double)s2 * g_U[r * 3 + 2];
+                    double xbp = xb[r] + t;
+                    d[r] = xbp - xa[r];
+                }
+                double d2 = d[0] * d[0] + d[1] * d[1];
+                if (dim == 3) d2 = d2 + d[2] * d[2];
+                if (d2 < best) {
+                    best = d2;
+                    del[0] = d[0];
+                    del[1] = d[1];
+                    del[2] = d[2];
+                }
+            }
+    return best;
+}
+
 static inline double canon_d2(int dim, const double *xa, const double *xb, const double *L, double *del)
 {
+    if (g_tric) return tric_d2(dim, xa, xb, del);
     del[0] = del[1] = del[2] = 0.0;
     for (int c = 0; c < dim; ++c) {
         double d0 = xb[c] - xa[c];
@@ -517,19 +584,43 @@ static inline double wrap1(double xc, int32_t *img, double Lc, double invLc)
     return Lc * fm;
 }
 
+/* src/boundary.jl:7-17 wrap_to_box for a general cell: frac = U^-1 x (row times vector, left to right) ; n = floor.(frac) ;
+ * image += Int.(n) ; x = U (frac - n). */
+static inline void wrap_tric(int dim, double *x, int32_t *img)
+{
+    double frac[3] = {0.0, 0.0, 0.0}, fm[3] = {0.0, 0.0, 0.0};
+    for (int r = 0; r < dim; ++r) {
+        double a = g_Uinv[r * 3 + 0] * x[0] + g_Uinv[r * 3 + 1] * x[1];
+        if (dim == 3) a = a + g_Uinv[r * 3 + 2] * x[2];
+        frac[r] = a;
+    }
+    for (int r = 0; r < dim; ++r) {
+        double nn = floor(frac[r]);
+        fm[r] = frac[r] - nn;
+        img[r] += (int32_t)nn;
+    }
+    for (int r = 0; r < dim; ++r) {
+        double a = g_U[r * 3 + 0] * fm[0] + g_U[r * 3 + 1] * fm[1];
+        if (dim == 3) a = a + g_U[r * 3 + 2] * fm[2];
+        x[r] = a;
+    }
+}
+
 /* src/integrate.jl:8-21 integrate_half!:  v += (f*dt)/2 ; x += v*dt ; x = wrap(x) */
 void oracle_integrate_half(int dim, int n, double *x, int32_t *img, double *v, const double *f, double dt,
                            const double *L)
 {
     double invL[3];
     for (int c = 0; c < dim; ++c) invL[c] = 1.0 / L[c];
-    for (int i = 0; i < n; ++i)
+    for (int i = 0; i < n; ++i) {
         for (int c = 0; c < dim; ++c) {
             size_t k = (size_t)i * dim + c;
             v[k] += f[k] * dt / 2.0;
             x[k] += v[k] * dt;
-            x[k] = wrap1(x[k], &img[k], L[c], invL[c]);
+            if (!g_tric) x[k] = wrap1(x[k], &img[k], L[c], invL[c]);
         }
+        if (g_tric) wrap_tric(dim, x + (size_t)i * dim, img + (size_t)i * dim);
+    }
 }
 
 /* src/integrate.jl:28-38 integrate_second_half! */

@@ -69,6 +69,10 @@ def lib():
         L.oracle_run.argtypes = [C.c_int, C.c_int, dp, ip, dp, dp, dp, dp, C.c_double, pp, C.c_double, C.c_int,
                                  C.c_double, C.c_double, dp, dp, dp, C.c_int, C.c_int, dp, C.c_int, C.c_int, dp]
         L.oracle_run.restype = C.c_int
+        L.oracle_set_cell.argtypes = [C.c_int, dp]
+        L.oracle_set_cell.restype = None
+        L.oracle_get_cell_inverse.argtypes = [dp]
+        L.oracle_get_cell_inverse.restype = None
         L.oracle_max_threads.argtypes = []
         L.oracle_max_threads.restype = C.c_int
         _lib = L
@@ -93,6 +97,36 @@ def evaluate(pot, r, s1, s2):
     return u.value, f.value
 
 
+_cell = None     # the general unit cell in force (set_cell), or None: the diagonal cell of each call's `box`
+
+
+class set_cell:
+    """with set_cell(U): ...  -- general (triclinic) unit cell, U's COLUMNS are the lattice vectors (src/boundary.jl:7-17,
+    src/initialization.jl:7-18).  Inside the block forces_brute and run(use_cells=False) use it (the `box` argument is
+    ignored); the linked-cell functions stay orthorhombic and must not be called."""
+
+    def __init__(self, U):
+        self.U = np.ascontiguousarray(U, dtype=np.float64)
+
+    def __enter__(self):
+        global _cell
+        d = self.U.shape[0]
+        lib().oracle_set_cell(d, _d(self.U))
+        _cell = self.U
+        return self
+
+    def __exit__(self, *exc):
+        global _cell
+        lib().oracle_set_cell(0, None)
+        _cell = None
+
+    @staticmethod
+    def inverse():
+        out = np.zeros(9)
+        lib().oracle_get_cell_inverse(_d(out))
+        return out.reshape(3, 3)
+
+
 def forces_brute(x, box, cutoff, pot, diam, want_pairs=False):
     """x: (N,d) array (row i = particle i; same memory as Julia's d x N column-major)."""
     x = _f64(x)
@@ -103,7 +137,12 @@ def forces_brute(x, box, cutoff, pot, diam, want_pairs=False):
     u, w = C.c_double(), C.c_double()
     pairs = None
     cap = 0
-    if want_pairs:
+    if want_pairs and _cell is not None:
+        # (no linked cells for a general cell: count with a first brute-force pass)
+        cap = lib().oracle_forces_brute(d, n, _d(x), _d(box), cutoff, C.byref(pot), _d(diam), _d(f.copy()), C.byref(u),
+                                        C.byref(w), None, 0)
+        pairs = np.zeros((max(cap, 1), 2), dtype=np.int32)
+    elif want_pairs:
         cap = lib().oracle_pairs_cells(d, n, _d(x), _d(box), cutoff, None, 0)
         pairs = np.zeros((max(cap, 1), 2), dtype=np.int32)
     npairs = lib().oracle_forces_brute(d, n, _d(x), _d(box), cutoff, C.byref(pot), _d(diam), _d(f), C.byref(u),

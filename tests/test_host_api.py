@@ -42,9 +42,14 @@ def test_create_argument_errors():
     assert lib.md_create(4, 100, box, 2.5, -1, ctypes.byref(h)) != 0
     assert b"dim" in lib.md_last_error(None)
     assert lib.md_create(3, 1, box, 2.5, -1, ctypes.byref(h)) != 0
+    # a general (triclinic) cell is accepted by md_create (tests/test_gpu_triclinic.py), refused by the slab decomposition,
+    # and a singular matrix is an argument error before any device is looked for
     tri = (ctypes.c_double * 9)(10, 0, 0, 1, 10, 0, 0, 0, 10)
-    assert lib.md_create(3, 100, tri, 2.5, -1, ctypes.byref(h)) != 0
+    assert lib.md_create_domain(3, 100, 100, tri, 2.5, -1, 0, 2, ctypes.byref(h)) != 0
     assert b"orthorhombic" in lib.md_last_error(None)
+    sing = (ctypes.c_double * 9)(10, 5, 0, 20, 10, 0, 0, 0, 10)
+    assert lib.md_create(3, 100, sing, 2.5, -1, ctypes.byref(h)) != 0
+    assert b"singular" in lib.md_last_error(None)
     assert lib.md_create(3, 100, box, -1.0, -1, ctypes.byref(h)) != 0
     assert lib.md_set_skin(None, 0.3) != 0      # null handle is an error, not a crash
 
@@ -282,16 +287,6 @@ def test_julia_binding_matches_the_header():
     for name in ("run_simulation!", "minimize!", "fire_minimize!", "write_to_file_lammps", "traj_name", "log_times",
                  "compress", "Brownian", "evaluate(p::PseudoHS", "evaluate(p::Polydisperse"):
         assert name in src
-
-
-def test_triclinic_unit_cell_is_refused_through_initialize_state(tmp_path):
-    """src/boundary.jl:7-17 and src/initialization.jl:7-18 take any cell matrix; this version builds its cell grid for
-    diagonal (orthorhombic) cells only and says so -- through the reference-level entry point, not only md_create."""
-    params = md.Parameters(0.5, 64, 0.001, md.LennardJones())
-    cell = np.array([[12.0, 2.0, 0.0], [0.0, 12.0, 0.0], [0.0, 0.0, 12.0]])
-    x = np.random.default_rng(0).uniform(0, 10, (64, 3))
-    with pytest.raises(md.MdhipError, match="orthorhombic"):
-        md.initialize_state(params, str(tmp_path), cutoff=2.5, positions=x, diameters=np.ones(64), unitcell=cell)
 
 
 def test_bench_launcher_starts_one_process_per_rank(tmp_path):

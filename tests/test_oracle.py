@@ -260,3 +260,46 @@ def test_pair_acceptance_is_reference_form(oracle):
         contributes = np.sqrt(ref) < 2.5
         assert contributes == (ref < dn)
         assert (np.abs(f[2 * k]).max() > 0.0) == contributes
+
+
+# ---------------------------------------------------------------------------------------------
+# General (triclinic) unit cell: oracle_set_cell (src/boundary.jl:7-17, src/initialization.jl:7-18).  The reference holds
+# no fixture for a skewed cell (parity with it is unpinned there); these pin the restatement against itself.
+# ---------------------------------------------------------------------------------------------
+def test_general_cell_with_a_diagonal_matrix_is_the_orthorhombic_result(oracle):
+    from tests.util import lj_system
+    s = lj_system(700)
+    pot = oracle.make_pot(0, [1.0, 1.0, 2.5])
+    f0, u0, w0, p0 = oracle.forces_brute(s["x"], s["box"], 2.5, pot, s["diam"], want_pairs=True)
+    with oracle.set_cell(np.diag(s["box"])):
+        f1, u1, w1, p1 = oracle.forces_brute(s["x"], s["box"], 2.5, pot, s["diam"], want_pairs=True)
+        inv = oracle.set_cell.inverse()
+    assert np.array_equal(p0, p1) and np.array_equal(f0, f1) and u0 == u1 and w0 == w1
+    assert np.array_equal(inv, np.diag(1.0 / s["box"]))
+    # and the flag is really off again
+    f2, u2, _, _ = oracle.forces_brute(s["x"], s["box"], 2.5, pot, s["diam"])
+    assert np.array_equal(f0, f2)
+
+
+def test_general_cell_same_lattice_same_physics(oracle):
+    """U M with M unimodular spans the same lattice: energies agree to rounding, and a short run from positions that
+    start outside the sheared cell unwraps to the same trajectory."""
+    from tests.util import lj_system
+    s = lj_system(600, kT=1.1)
+    pot = oracle.make_pot(0, [1.0, 1.0, 2.5])
+    U = np.diag(s["box"])
+    M = np.array([[1.0, 1.0, 0.0], [0.0, 1.0, 0.0], [0.0, -1.0, 1.0]])
+    res = []
+    for cell in (U, U @ M):
+        with oracle.set_cell(cell):
+            x, img = s["x"].copy(), s["img"].copy()
+            oracle.integrate_half(x, img, np.zeros_like(x), np.zeros_like(x), 0.0, s["box"])      # wrap into the cell
+            fr = np.linalg.solve(cell, x.T).T
+            assert fr.min() >= -1e-13 and fr.max() < 1 + 1e-13
+            assert np.abs(x + img @ cell.T - s["x"]).max() < 1e-12
+            f, u, w, npairs = oracle.forces_brute(x, s["box"], 2.5, pot, s["diam"])
+            r = oracle.run(x, img, s["v"], f, s["diam"], s["box"], 2.5, pot, 0.002, 15, use_cells=False)
+            res.append((u, w, npairs, r["x"] + r["img"] @ cell.T, r["v"]))
+    a, b = res
+    assert a[2] == b[2] and abs(a[0] - b[0]) < 1e-11 * abs(a[0]) and abs(a[1] - b[1]) < 1e-11 * abs(a[1])
+    assert np.abs(a[3] - b[3]).max() < 1e-10 and np.abs(a[4] - b[4]).max() < 1e-10
