@@ -275,7 +275,11 @@ __global__ void __launch_bounds__(MD_BLOCK)
     ids[k] = s.id[k];
 }
 
-__global__ void k_reset_viol(Scalars *sc) { sc->first_viol = MD_NO_VIOLATION; }
+__global__ void k_reset_viol(Scalars *sc)
+{
+    sc->first_viol = MD_NO_VIOLATION;
+    sc->comm_error = 0;
+}
 
 // ------------------------------------------------------------------------------------------
 // asynchronous stepping: the words the caller all-reduces between the phases of a step
@@ -338,19 +342,138 @@ __global__ void k_dom_global_finalize(const double *__restrict__ sums, int want_
 //     k_step_tile(t)  ->  k_dom_post(t)  ->  all-reduce {sum v'^2, U, W, violated}  ->  send/recv records
 //                     ->  k_dom_adopt(t)  (records into the x-halo slots; violation adopted globally, or the
 //                         global K / U / W and the Bussi scale of step t formed: src/thermostat.jl:36-40)
-// Two small launches and two collectives per step instead of four launches and three collectives.
+// Two small launches and two collectives per step instead of four launches and three collectives -- or, with the
+// direct peer exchange below, two small launches and no collective at all.
 // ------------------------------------------------------------------------------------------
+// ---- direct peer exchange (round 3) --------------------------------------------------------------------------------
+// The two collectives of a fused slab step can be replaced by ONE-SIDED STORES over xGMI: every rank owns a "mailbox" in
+// fine-grained device memory that its peers have mapped (hipIpc handles, exchanged once in md_dom_comm_init), and
+//   k_dom_post   stores this rank's four sums into every peer's mailbox and the boundary particles' records straight into
+//                the two neighbours' receive planes, then raises the matching flags (release, system scope);
+//   k_dom_adopt  waits (bounded) for the flags of its own mailbox, adds the ranks' sums in rank order -- the same bits on
+//                every rank -- and scatters the records as before.
+// No library call, no extra launch: a step is k_step_tile, k_dom_post, k_dom_adopt.  Flags carry the exchange's sequence
+// number (monotone, never reset; all ranks count the same exchanges); payloads alternate between two planes by its parity:
+// a rank's put number s + 1 follows, in stream order, its own wait number s, which saw the peer's put number s, which
+// follows the peer's adopt number s - 1 -- the last reader of plane (s + 1) & 1.  The sums handshake runs on EVERY exchange
+// (all ranks with all ranks), which is what bounds the skew between ranks that are not neighbours.
+// A rank that fails stores MD_P2P_POISON into the flags it owns at its peers: they stop waiting and report comm_error 2.
+constexpr int MD_P2P_MAXR = 16;
+constexpr unsigned long long MD_P2P_POISON = ~0ull;
+struct P2pPut {
+    int on, nranks;
+    unsigned long long seq;
+    double *sum_slot[MD_P2P_MAXR];             // peer r's slot for THIS rank's {sum v'^2, U, W, violated}, plane seq & 1
+    unsigned long long *sum_flag[MD_P2P_MAXR]; // peer r's flag for this rank's sums
+    unsigned long long *rec_flag[2];           // the left neighbour's "records from my right", the right one's "from my left"
+    unsigned *done;                            // local: packing blocks that have finished
+};
+struct P2pGet {
+    int on, nranks;
+    unsigned long long seq;
+    const double *sum_slot;                // this rank's mailbox: [nranks][4], plane seq & 1
+    const unsigned long long *sum_flag;    // [nranks] flags, MD_P2P_FLAG_WORDS apart
+    const unsigned long long *rec_flag[2]; // records from the left / from the right neighbour
+    long long timeout;                     // wall_clock64() ticks (100 MHz)
+};
+constexpr int MD_P2P_FLAG_WORDS = 16; // one flag per 128-byte line
+
+// Every word of the exchange is written and read with SYSTEM-SCOPE RELAXED accesses (sc0 sc1: written through to / read
+// from memory, never served by an L2), and ordered by waiting for the stores' acknowledgements (s_waitcnt vmcnt(0)) before
+// the flag is raised -- NOT by release / acquire fences: a system-scope release writes back every dirty line of the L2
+// (the step kernel has just left tens of MB there) and an acquire invalidates it; measured at 20 and 10 us per kernel.
+__device__ __forceinline__ void p2p_st(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ double p2p_ld(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void p2p_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void p2p_raise(unsigned long long *flag, unsigned long long seq)
+{
+    __hip_atomic_store(flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// 0: delivered; 1: timed out; 2: the peer reported a failure
+__device__ __forceinline__ int p2p_wait(const unsigned long long *flag, unsigned long long seq, long long t0, long long timeout)
+{
+    for (;;) {
+        unsigned long long f = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (f == MD_P2P_POISON) return 2;
+        if (f >= seq) return 0;
+        if (wall_clock64() - t0 > timeout) return 1;
+        __builtin_amdgcn_s_sleep(4);
+    }
+}
+// this rank's four sums into every peer's mailbox (one thread per peer), flag after the payload has been acknowledged
+__device__ __forceinline__ void p2p_put_sums(const P2pPut &pp, double a, double b, double c, double v)
+{
+    const int r = threadIdx.x;
+    if (r < pp.nranks) {
+        double *o = pp.sum_slot[r];
+        p2p_st(o + 0, a);
+        p2p_st(o + 1, b);
+        p2p_st(o + 2, c);
+        p2p_st(o + 3, v);
+        p2p_drain();
+        p2p_raise(pp.sum_flag[r], pp.seq);
+    }
+}
+// every packing block calls this after its stores: the last one to arrive raises the two record flags
+__device__ __forceinline__ void p2p_records_done(const P2pPut &pp, unsigned nblocks_packing)
+{
+    p2p_drain(); // this thread's record words have arrived
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned prev = __hip_atomic_fetch_add(pp.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (prev == nblocks_packing - 1) {
+            __hip_atomic_store(pp.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (the next launch is the next user)
+            p2p_raise(pp.rec_flag[0], pp.seq);
+            p2p_raise(pp.rec_flag[1], pp.seq);
+        }
+    }
+}
+// every block of the receiving kernel: wait for both neighbours' records; block 0 also for every rank's sums, which it
+// adds in rank order into kuw[4] (shared).  Returns 0 when everything arrived; sets sc->comm_error otherwise.
+__device__ __forceinline__ int p2p_collect(const P2pGet &pg, Scalars *sc, double *kuw /* shared, 4 */, int *sh_state /* shared */)
+{
+    if (threadIdx.x == 0) {
+        int st = 0;
+        // (after one failure nothing waits again: the window drains within one timeout whatever went wrong)
+        if (__hip_atomic_load(&sc->comm_error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) st = 3;
+        const long long t0 = wall_clock64();
+        if (!st) st = p2p_wait(pg.rec_flag[0], pg.seq, t0, pg.timeout);
+        if (!st) st = p2p_wait(pg.rec_flag[1], pg.seq, t0, pg.timeout);
+        if (!st && blockIdx.x == 0) {
+            double a = 0.0, b = 0.0, c = 0.0, v = 0.0;
+            for (int r = 0; r < pg.nranks && !st; ++r) {
+                st = p2p_wait(pg.sum_flag + (size_t)r * MD_P2P_FLAG_WORDS, pg.seq, t0, pg.timeout);
+                if (st) break;
+                const double *q = pg.sum_slot + 4 * (size_t)r;
+                a += p2p_ld(q + 0);
+                b += p2p_ld(q + 1);
+                c += p2p_ld(q + 2);
+                v += p2p_ld(q + 3);
+            }
+            kuw[0] = a;
+            kuw[1] = b;
+            kuw[2] = c;
+            kuw[3] = v;
+        }
+        if (st == 1 || st == 2) atomicMax(&sc->comm_error, st);
+        *sh_state = st;
+    }
+    __syncthreads(); // (the record words are read after this barrier, with p2p_ld: from memory, not from a cached line)
+    return *sh_state;
+}
+
 // block 0: this rank's fixed-order sums + its violation indicator; blocks >= 1: pack the boundary particles' records
-__global__ void __launch_bounds__(MD_BLOCK)
-    k_dom_post(int nblk, const double *__restrict__ partials, int want_uw, double *__restrict__ kuw4, const Scalars *sc,
-               int step, int n0, int n1, const int32_t *__restrict__ slot0, const int32_t *__restrict__ slot1,
-               const double2 *__restrict__ rec, size_t rstride, double shift0, double shift1,
-               double *__restrict__ out0, double *__restrict__ out1, int what /* 1 = sums, 2 = pack, 3 = both */)
+// (six planes of n doubles per side: consecutive lanes store consecutive words, also when the target is a peer's memory)
+__device__ __forceinline__ void
+dom_post_body(int nblk, const double *__restrict__ partials, int want_uw, double *__restrict__ kuw4, const Scalars *sc,
+              int step, int n0, int n1, const int32_t *__restrict__ slot0, const int32_t *__restrict__ slot1,
+              const double2 *__restrict__ rec, size_t rstride, double shift0, double shift1,
+              double *__restrict__ out0, double *__restrict__ out1, int what /* 1 = sums, 2 = pack, 3 = both */, const P2pPut &pp,
+              unsigned nblocks_packing, double *red /* shared, 16 */)
 {
     const int fv = sc->first_viol;
     if (blockIdx.x == 0) {
         if (!(what & 1)) return;
-        __shared__ double red[16];
         double a = 0.0, b = 0.0, c = 0.0;
         if (!(fv < step)) {
             a = strided_sum<16>(partials, nblk);
@@ -362,54 +485,98 @@ __global__ void __launch_bounds__(MD_BLOCK)
         a = block_sum(a, red);
         b = block_sum(b, red);
         c = block_sum(c, red);
+        const double v = (fv == step) ? 1.0 : 0.0; // this rank's displacement check failed in this step
         if (threadIdx.x == 0) {
             kuw4[0] = a;
             kuw4[1] = b;
             kuw4[2] = c;
-            kuw4[3] = (fv == step) ? 1.0 : 0.0; // this rank's displacement check failed in this step
+            kuw4[3] = v;
+        }
+        if (pp.on) {
+            // (block_sum leaves the total in every thread)
+            p2p_put_sums(pp, a, b, c, v);
         }
         return;
     }
-    if (fv < step || !(what & 2)) return; // (an earlier step was violated: this one did not run)
-    int j = (blockIdx.x - 1) * blockDim.x + threadIdx.x;
-    const int32_t *slot = slot0;
-    double *out = out0;
-    double shift = shift0;
-    if (j >= n0) {
-        j -= n0;
-        if (j >= n1) return;
-        slot = slot1;
-        out = out1;
-        shift = shift1;
+    if (!(what & 2)) return;
+    // (an earlier step was violated: this one did not run and packs nothing -- but the flags still travel)
+    if (!(fv < step)) {
+        int j = (blockIdx.x - 1) * blockDim.x + threadIdx.x;
+        const int32_t *slot = slot0;
+        double *out = out0;
+        double shift = shift0;
+        int nn = n0;
+        bool live = true;
+        if (j >= n0) {
+            j -= n0;
+            live = j < n1;
+            slot = slot1;
+            out = out1;
+            shift = shift1;
+            nn = n1;
+        }
+        if (live) {
+            const size_t k = (size_t)slot[j];
+            double2 a0 = rec[k], a1 = rec[rstride + k], a2 = rec[2 * rstride + k];
+            double *o = out + j;
+            const size_t ns = (size_t)nn;
+            if (pp.on) {
+                p2p_st(o, a0.x + shift);
+                p2p_st(o + ns, a0.y);
+                p2p_st(o + 2 * ns, a1.x);
+                p2p_st(o + 3 * ns, a1.y);
+                p2p_st(o + 4 * ns, a2.x);
+                p2p_st(o + 5 * ns, a2.y);
+            } else {
+                o[0] = a0.x + shift;
+                o[ns] = a0.y;
+                o[2 * ns] = a1.x;
+                o[3 * ns] = a1.y;
+                o[4 * ns] = a2.x;
+                o[5 * ns] = a2.y;
+            }
+        }
     }
-    const size_t k = (size_t)slot[j];
-    double2 a0 = rec[k], a1 = rec[rstride + k], a2 = rec[2 * rstride + k];
-    double *o = out + 6 * (size_t)j;
-    o[0] = a0.x + shift;
-    o[1] = a0.y;
-    o[2] = a1.x;
-    o[3] = a1.y;
-    o[4] = a2.x;
-    o[5] = a2.y;
+    if (pp.on) p2p_records_done(pp, nblocks_packing);
+}
+__global__ void __launch_bounds__(MD_BLOCK)
+    k_dom_post(int nblk, const double *__restrict__ partials, int want_uw, double *__restrict__ kuw4, const Scalars *sc,
+               int step, int n0, int n1, const int32_t *__restrict__ slot0, const int32_t *__restrict__ slot1,
+               const double2 *__restrict__ rec, size_t rstride, double shift0, double shift1,
+               double *__restrict__ out0, double *__restrict__ out1, int what, P2pPut pp)
+{
+    __shared__ double red[16];
+    dom_post_body(nblk, partials, want_uw, kuw4, sc, step, n0, n1, slot0, slot1, rec, rstride, shift0, shift1, out0, out1, what, pp,
+                  gridDim.x - 1, red);
 }
 
-__global__ void __launch_bounds__(MD_BLOCK)
-    k_dom_adopt(int n0, int n1, const int32_t *__restrict__ xh_slot, const double *__restrict__ in0,
-                const double *__restrict__ in1, double2 *__restrict__ rec, size_t rstride, int planes,
-                const double4 *__restrict__ pos, const double *__restrict__ kuw4, int want_uw, int nvt, double nf,
-                double term1, const double *__restrict__ kt, const double *__restrict__ r1,
-                const double *__restrict__ r2, Scalars *sc, int step, int finalize)
+__device__ __forceinline__ void
+dom_adopt_body(int n0, int n1, const int32_t *__restrict__ xh_slot, const double *__restrict__ in0,
+               const double *__restrict__ in1, double2 *__restrict__ rec, size_t rstride, int planes,
+               const double4 *__restrict__ pos, const double *__restrict__ kuw4, int want_uw, int nvt, double nf,
+               double term1, const double *__restrict__ kt, const double *__restrict__ r1,
+               const double *__restrict__ r2, Scalars *sc, int step, int finalize, const P2pGet &pg, double *kuw_sh /* shared, 4 */,
+               int *comm_state /* shared */)
 {
+    const double *kuw = kuw4;
+    if (pg.on) {
+        if (p2p_collect(pg, sc, kuw_sh, comm_state) != 0) {
+            // nothing of this exchange may be used; every later step of the window skips itself
+            if (blockIdx.x == 0 && threadIdx.x == 0 && step < sc->first_viol) sc->first_viol = step < 0 ? 0 : step;
+            return;
+        }
+        kuw = kuw_sh;
+    }
     const int fv = sc->first_viol; // (thread 0 may set it to `step` below: either value reads the same here)
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j == 0 && finalize && !(fv < step)) {
-        if (kuw4[3] > 0.0) {
+        if (kuw[3] > 0.0) {
             if (step < sc->first_viol) sc->first_viol = step; // some rank's check failed: every rank stops here
         } else {
-            double K = kuw4[0] / 2.0;
+            double K = kuw[0] / 2.0;
             if (want_uw) {
-                sc->U = kuw4[1] / 2.0; // every pair was evaluated from both ends
-                sc->W = kuw4[2] / 2.0;
+                sc->U = kuw[1] / 2.0; // every pair was evaluated from both ends
+                sc->W = kuw[2] / 2.0;
             }
             if (nvt) {
                 double tc = 2.0 * K / nf;
@@ -427,12 +594,95 @@ __global__ void __launch_bounds__(MD_BLOCK)
     }
     if (fv < step) return; // (this step did not run: its buffer set is the state to fall back to -- leave it alone)
     if (j >= n0 + n1) return;
-    const double *in = j < n0 ? in0 + 6 * (size_t)j : in1 + 6 * (size_t)(j - n0);
+    const bool lft = j < n0;
+    const double *in = lft ? in0 + j : in1 + (j - n0);
+    const size_t ns = (size_t)(lft ? n0 : n1);
     const size_t k = (size_t)xh_slot[j];
-    rec[k] = make_double2(in[0], in[1]);
-    rec[rstride + k] = make_double2(in[2], in[3]);
-    rec[2 * rstride + k] = make_double2(in[4], in[5]);
+    double w[6];
+    if (pg.on) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) w[q] = p2p_ld(in + q * ns);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) w[q] = in[q * ns];
+    }
+    rec[k] = make_double2(w[0], w[1]);
+    rec[rstride + k] = make_double2(w[2], w[3]);
+    rec[2 * rstride + k] = make_double2(w[4], w[5]);
     if (planes > 3) rec[3 * rstride + k] = make_double2(pos[k].w, 0.0);
+}
+__global__ void __launch_bounds__(MD_BLOCK)
+    k_dom_adopt(int n0, int n1, const int32_t *__restrict__ xh_slot, const double *__restrict__ in0,
+                const double *__restrict__ in1, double2 *__restrict__ rec, size_t rstride, int planes,
+                const double4 *__restrict__ pos, const double *__restrict__ kuw4, int want_uw, int nvt, double nf,
+                double term1, const double *__restrict__ kt, const double *__restrict__ r1,
+                const double *__restrict__ r2, Scalars *sc, int step, int finalize, P2pGet pg)
+{
+    __shared__ double kuw_sh[4];
+    __shared__ int comm_state;
+    dom_adopt_body(n0, n1, xh_slot, in0, in1, rec, rstride, planes, pos, kuw4, want_uw, nvt, nf, term1, kt, r1, r2, sc, step,
+                   finalize, pg, kuw_sh, &comm_state);
+}
+
+// Direct peer exchange: post and adopt in ONE launch.  Every block first does its share of the post (block 0 the sums,
+// blocks 1 .. post_blocks-1 the packing), then waits on this rank's mailbox and adopts.  No block's post depends on a wait,
+// and the whole grid is resident at once (the host checks: at most 1024 blocks), so the waits cannot starve the stores
+// they wait for -- neither a peer's nor, with one rank, this rank's own.
+struct DomPostArgs {
+    int nblk;
+    const double *partials;
+    double *kuw4;
+    int n0, n1;
+    const int32_t *slot0, *slot1;
+    double shift0, shift1;
+    double *out0, *out1;
+    int post_blocks; // 1 + packing blocks
+};
+struct DomAdoptArgs {
+    int n0, n1;
+    const int32_t *xh_slot;
+    const double *in0, *in1;
+    int planes;
+    const double4 *pos;
+    int nvt;
+    double nf, term1;
+    const double *kt, *r1, *r2;
+    int adopt_blocks;
+};
+__global__ void __launch_bounds__(MD_BLOCK)
+    k_dom_exchange(DomPostArgs pa, DomAdoptArgs aa, const double2 *rec_out, double2 *rec_in, size_t rstride,
+                   int want_uw, Scalars *sc, int step, int finalize, P2pPut pp, P2pGet pg)
+{
+    __shared__ double red[16];
+    __shared__ double kuw_sh[4];
+    __shared__ int comm_state;
+    if ((int)blockIdx.x < pa.post_blocks)
+        dom_post_body(pa.nblk, pa.partials, want_uw, pa.kuw4, sc, step, pa.n0, pa.n1, pa.slot0, pa.slot1, rec_out, rstride, pa.shift0,
+                      pa.shift1, pa.out0, pa.out1, 3, pp, (unsigned)(pa.post_blocks - 1), red);
+    if ((int)blockIdx.x < aa.adopt_blocks)
+        dom_adopt_body(aa.n0, aa.n1, aa.xh_slot, aa.in0, aa.in1, rec_in, rstride, aa.planes, aa.pos, pa.kuw4, want_uw, aa.nvt, aa.nf,
+                       aa.term1, aa.kt, aa.r1, aa.r2, sc, step, finalize, pg, kuw_sh, &comm_state);
+}
+
+// md_dom_comm_init's rehearsal of the direct exchange: one exchange with no records and known sums
+__global__ void __launch_bounds__(MD_BLOCK) k_p2p_hello_put(P2pPut pp, double a)
+{
+    if (blockIdx.x == 0) {
+        p2p_put_sums(pp, a, 1.0, 0.0, 0.0);
+        return;
+    }
+    p2p_records_done(pp, gridDim.x - 1);
+}
+__global__ void __launch_bounds__(MD_BLOCK) k_p2p_hello_get(P2pGet pg, Scalars *sc, double *out4)
+{
+    __shared__ double kuw_sh[4];
+    __shared__ int comm_state;
+    int st = p2p_collect(pg, sc, kuw_sh, &comm_state);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        out4[0] = st == 0 ? kuw_sh[0] : -1.0;
+        out4[1] = st == 0 ? kuw_sh[1] : -1.0;
+        out4[2] = (double)st;
+    }
 }
 
 // after the fused window's buffer sets changed roles: the x-halo slots of the position array now in use take the

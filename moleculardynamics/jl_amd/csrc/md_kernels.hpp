@@ -87,6 +87,7 @@ struct Scalars {
     int halo_overflow; // a tile's halo did not fit its slot table
     int dbg_rmax, dbg_smax; // fused build: largest cell range / staged set of a tile
     unsigned long long d1max2_bits; // max over particles of |x(prune) - x(build)|^2, as double bits
+    int comm_error; // direct peer exchange (md_domain.hpp): 1 = a peer did not deliver in time, 2 = a peer reported a failure
 };
 
 // ------------------------------------------------------------------------------------------

@@ -126,6 +126,19 @@ struct md_ctx {
         // a fused window refreshes the x-halo particles' state RECORDS every step, not their pos[] entries: until the
         // next list build (or a classic step's coordinate exchange) md_dom_forces would read stale neighbour coordinates
         bool xhalo_pos_stale = false;
+        // direct peer exchange (md_domain.hpp): this rank's mailbox, its peers' mailboxes as mapped here
+        struct P2p {
+            bool on = false;
+            char *mail = nullptr;
+            int64_t cap = 0; // records per receive plane of THIS rank's mailbox
+            char *peer[MD_P2P_MAXR] = {};
+            bool opened[MD_P2P_MAXR] = {};
+            int64_t peer_cap[MD_P2P_MAXR] = {};
+            unsigned long long seq = 0; // exchanges so far (all ranks count the same ones)
+            unsigned *done = nullptr;
+            long long timeout = 0;
+            bool window = false; // the window being enqueued uses it (agreed by all ranks)
+        } p2p;
     } dom;
     double L[3] = {1, 1, 1};
     // general (triclinic) unit cell: A = the cell matrix (row-major 3 x 3, columns = lattice vectors), Ainv its inverse,
@@ -1461,6 +1474,8 @@ int md_create_domain(int dim, int64_t n_global, int64_t n_cap, const double *box
     return create_common(dim, n_global, n_cap, true, rank, nranks, box, list_cutoff, device_id, out);
 }
 
+static void dom_p2p_teardown(md_ctx *c);
+
 int md_destroy(md_ctx *ctx)
 {
     if (!ctx) return 0;
@@ -1482,6 +1497,7 @@ int md_destroy(md_ctx *ctx)
         (void)hipEventDestroy(ctx->dom.ev_go);
         (void)hipEventDestroy(ctx->dom.ev_int);
     }
+    dom_p2p_teardown(ctx);
     if (ctx->dom.comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(ctx->dom.comm);
     ctx->dom.comm = nullptr;
     for (auto &p : ctx->prof_ev) {
@@ -2955,6 +2971,8 @@ int md_dom_comm_unique_id(const char *rccl_path, void *id128)
     }
 }
 
+static void dom_p2p_setup(md_ctx *ctx);
+
 int md_dom_comm_init(md_ctx *ctx, const char *rccl_path, const void *id128)
 {
     API_BEGIN
@@ -2985,6 +3003,7 @@ int md_dom_comm_init(md_ctx *ctx, const char *rccl_path, const void *id128)
     double want = 0.5 * d.nranks * (d.nranks + 1.0);
     if (hv[0] != want || hv[1] != (double)d.nranks || hf != 7)
         throw HipError("md_dom_comm_init: RCCL self-test returned wrong values");
+    dom_p2p_setup(ctx);
     API_END
 }
 
@@ -3032,12 +3051,242 @@ int md_dom_invalidate_inner(md_ctx *ctx)
 
 // A failure on this rank between collectives would leave its peers blocked inside theirs: abort the communicator
 // first so that they fail fast instead of hanging (the handle needs md_dom_comm_init again).
+// ---- direct peer exchange: mailbox layout, set-up, tear-down (md_domain.hpp "direct peer exchange") -----------------
+// mailbox of a rank:  [2 record flags | nranks sum flags] (one per 128-byte line)  [2 planes][nranks][4] sums
+//                     [from-left, from-right][2 planes][6][cap] record words
+static size_t p2p_round(size_t v) { return (v + 255) & ~(size_t)255; }
+static size_t p2p_off_rec_flag(int side) { return (size_t)side * 128; }
+static size_t p2p_off_sum_flag(int r) { return (size_t)(2 + r) * 128; }
+static size_t p2p_off_sums(int nranks, int plane, int r) { return p2p_round((size_t)(2 + nranks) * 128) + ((size_t)plane * nranks + r) * 32; }
+static size_t p2p_off_recs(int nranks, int64_t cap, int side, int plane)
+{
+    return p2p_round(p2p_off_sums(nranks, 2, 0)) + (size_t)(side * 2 + plane) * 6 * (size_t)cap * sizeof(double);
+}
+static size_t p2p_bytes(int nranks, int64_t cap) { return p2p_off_recs(nranks, cap, 2, 0); }
+
+static void dom_p2p_teardown(md_ctx *c)
+{
+    auto &q = c->dom.p2p;
+    for (int r = 0; r < MD_P2P_MAXR; ++r) {
+        if (q.opened[r] && q.peer[r]) (void)hipIpcCloseMemHandle(q.peer[r]);
+        q.opened[r] = false;
+        q.peer[r] = nullptr;
+    }
+    if (q.mail) (void)hipFree(q.mail);
+    if (q.done) (void)hipFree(q.done);
+    q.mail = nullptr;
+    q.done = nullptr;
+    q.on = false;
+    q.window = false;
+    q.seq = 0;
+}
+
+// a failing rank tells its peers: every flag this rank owns in their mailboxes takes the poison value, so that a peer
+// waiting for this rank stops at once (comm_error 2) instead of running into its timeout.  Never throws.
+static void dom_p2p_poison(md_ctx *c)
+{
+    auto &d = c->dom;
+    auto &q = d.p2p;
+    if (!q.on) return;
+    const unsigned long long poison = MD_P2P_POISON;
+    const int left = (d.rank + d.nranks - 1) % d.nranks, right = (d.rank + 1) % d.nranks;
+    for (int r = 0; r < d.nranks; ++r)
+        if (q.peer[r]) (void)hipMemcpy(q.peer[r] + p2p_off_sum_flag(d.rank), &poison, sizeof poison, hipMemcpyHostToDevice);
+    if (q.peer[left]) (void)hipMemcpy(q.peer[left] + p2p_off_rec_flag(1), &poison, sizeof poison, hipMemcpyHostToDevice);
+    if (q.peer[right]) (void)hipMemcpy(q.peer[right] + p2p_off_rec_flag(0), &poison, sizeof poison, hipMemcpyHostToDevice);
+    q.on = false; // (the sequence numbers are out of step from here on: md_dom_comm_init builds a fresh set)
+}
+
+static P2pPut dom_p2p_put_args(md_ctx *c, unsigned long long seq)
+{
+    auto &d = c->dom;
+    auto &q = d.p2p;
+    P2pPut a{};
+    a.on = 1;
+    a.nranks = d.nranks;
+    a.seq = seq;
+    const int plane = (int)(seq & 1ull);
+    for (int r = 0; r < d.nranks; ++r) {
+        a.sum_slot[r] = (double *)(q.peer[r] + p2p_off_sums(d.nranks, plane, d.rank));
+        a.sum_flag[r] = (unsigned long long *)(q.peer[r] + p2p_off_sum_flag(d.rank));
+    }
+    const int left = (d.rank + d.nranks - 1) % d.nranks, right = (d.rank + 1) % d.nranks;
+    a.rec_flag[0] = (unsigned long long *)(q.peer[left] + p2p_off_rec_flag(1));  // the left neighbour's "from my right"
+    a.rec_flag[1] = (unsigned long long *)(q.peer[right] + p2p_off_rec_flag(0)); // the right neighbour's "from my left"
+    a.done = q.done;
+    return a;
+}
+static P2pGet dom_p2p_get_args(md_ctx *c, unsigned long long seq, long long timeout)
+{
+    auto &d = c->dom;
+    auto &q = d.p2p;
+    P2pGet a{};
+    a.on = 1;
+    a.nranks = d.nranks;
+    a.seq = seq;
+    a.sum_slot = (const double *)(q.mail + p2p_off_sums(d.nranks, (int)(seq & 1ull), 0));
+    a.sum_flag = (const unsigned long long *)(q.mail + p2p_off_sum_flag(0));
+    a.rec_flag[0] = (const unsigned long long *)(q.mail + p2p_off_rec_flag(0));
+    a.rec_flag[1] = (const unsigned long long *)(q.mail + p2p_off_rec_flag(1));
+    a.timeout = timeout;
+    return a;
+}
+// where this rank's records for a neighbour go (side 0: to the left neighbour, 1: to the right), and where its own arrive
+static double *dom_p2p_send_plane(md_ctx *c, int side, unsigned long long seq)
+{
+    auto &d = c->dom;
+    const int peer = side == 0 ? (d.rank + d.nranks - 1) % d.nranks : (d.rank + 1) % d.nranks;
+    // (what goes to the left neighbour is what it receives "from the right")
+    return (double *)(d.p2p.peer[peer] + p2p_off_recs(d.nranks, d.p2p.peer_cap[peer], side == 0 ? 1 : 0, (int)(seq & 1ull)));
+}
+static double *dom_p2p_recv_plane(md_ctx *c, int side, unsigned long long seq)
+{
+    auto &d = c->dom;
+    return (double *)(d.p2p.mail + p2p_off_recs(d.nranks, d.p2p.cap, side, (int)(seq & 1ull)));
+}
+
+// Collective (called from md_dom_comm_init, after the communicator's own self-test).  Every step that can fail on some
+// rank only lowers `ok`; the ranks agree on the outcome (all-reduce MIN) and either all use the direct exchange or none.
+static void dom_p2p_setup(md_ctx *ctx)
+{
+    auto &d = ctx->dom;
+    auto &q = d.p2p;
+    dom_p2p_teardown(ctx);
+    hipStream_t st = ctx->stream;
+    int ok = 1;
+    const char *why = "";
+    if (const char *e = getenv("MDHIP_DOM_P2P"))
+        if (e[0] == '0') {
+            ok = 0;
+            why = "MDHIP_DOM_P2P=0";
+        }
+    if (d.nranks > MD_P2P_MAXR) {
+        ok = 0;
+        why = "more ranks than mailbox slots";
+    }
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
+    const int R = d.nranks;
+    q.cap = ctx->ncap;
+    hipIpcMemHandle_t mine;
+    memset(&mine, 0, sizeof mine);
+    if (ok) {
+        const size_t bytes = p2p_bytes(R, q.cap);
+        if (hipExtMallocWithFlags((void **)&q.mail, bytes, hipDeviceMallocFinegrained) != hipSuccess || !q.mail) {
+            (void)hipGetLastError();
+            q.mail = nullptr;
+            ok = 0;
+            why = "no fine-grained device memory";
+        } else {
+            HIPCHK(hipMemsetAsync(q.mail, 0, p2p_off_recs(R, q.cap, 0, 0), st)); // flags and sums
+            HIPCHK(hipMalloc((void **)&q.done, sizeof(unsigned)));
+            HIPCHK(hipMemsetAsync(q.done, 0, sizeof(unsigned), st));
+            HIPCHK(hipStreamSynchronize(st));
+            if (R > 1 && hipIpcGetMemHandle(&mine, q.mail) != hipSuccess) {
+                (void)hipGetLastError();
+                ok = 0;
+                why = "hipIpcGetMemHandle failed";
+            }
+        }
+    }
+    // handles and capacities travel through the communicator: rank r's 64 bytes as 64 doubles, everyone else adds zeros
+    DBuf<double> tmp;
+    tmp.alloc(64);
+    std::vector<hipIpcMemHandle_t> handles(R);
+    std::vector<double> caps(R, 0.0);
+    if (R > 1) {
+        for (int r = 0; r < R; ++r) {
+            double h[64];
+            for (int i = 0; i < 64; ++i) h[i] = (r == d.rank && ok) ? (double)((const unsigned char *)&mine)[i] : 0.0;
+            HIPCHK(hipMemcpyAsync(tmp.p, h, sizeof h, hipMemcpyHostToDevice, st));
+            g_rccl.check(g_rccl.AllReduce(tmp.p, tmp.p, 64, ncclFloat64, ncclSum, d.comm, st), "ncclAllReduce(mailbox handle)");
+            HIPCHK(hipMemcpyAsync(h, tmp.p, sizeof h, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            for (int i = 0; i < 64; ++i) ((unsigned char *)&handles[r])[i] = (unsigned char)h[i];
+        }
+        double h[64] = {};
+        h[d.rank] = ok ? (double)q.cap : 0.0;
+        HIPCHK(hipMemcpyAsync(tmp.p, h, sizeof h, hipMemcpyHostToDevice, st));
+        g_rccl.check(g_rccl.AllReduce(tmp.p, tmp.p, R, ncclFloat64, ncclSum, d.comm, st), "ncclAllReduce(mailbox capacity)");
+        HIPCHK(hipMemcpyAsync(h, tmp.p, sizeof h, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        for (int r = 0; r < R; ++r) {
+            caps[r] = h[r];
+            if (!(h[r] > 0.0) && ok) {
+                ok = 0;
+                why = "a peer has no mailbox";
+            }
+        }
+    } else {
+        caps[0] = (double)q.cap;
+    }
+    if (ok) {
+        for (int r = 0; r < R; ++r) {
+            q.peer_cap[r] = (int64_t)caps[r];
+            if (r == d.rank) {
+                q.peer[r] = q.mail;
+                continue;
+            }
+            void *pp = nullptr;
+            if (hipIpcOpenMemHandle(&pp, handles[r], hipIpcMemLazyEnablePeerAccess) != hipSuccess || !pp) {
+                (void)hipGetLastError();
+                ok = 0;
+                why = "hipIpcOpenMemHandle failed (no peer access to that device?)";
+                break;
+            }
+            q.peer[r] = (char *)pp;
+            q.opened[r] = true;
+        }
+    }
+    // rehearsal: one exchange without records, known sums, short timeout.  (Every rank runs it or none: a rank that
+    // cannot would leave the others waiting, so the decision so far is agreed on first.)
+    auto agree = [&](int v) {
+        int32_t hf = v;
+        HIPCHK(hipMemcpyAsync(d.own_flag.p, &hf, sizeof hf, hipMemcpyHostToDevice, st));
+        g_rccl.check(g_rccl.AllReduce(d.own_flag.p, d.own_flag.p, 1, ncclInt32, ncclMin, d.comm, st), "ncclAllReduce(direct exchange)");
+        HIPCHK(hipMemcpyAsync(&hf, d.own_flag.p, sizeof hf, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        return (int)hf;
+    };
+    int all = agree(ok);
+    if (all) {
+        q.on = true;
+        q.seq = 1;
+        k_reset_viol<<<1, 1, 0, st>>>(ctx->scal.p);
+        k_p2p_hello_put<<<2, MD_BLOCK, 0, st>>>(dom_p2p_put_args(ctx, q.seq), (double)(d.rank + 1));
+        k_p2p_hello_get<<<2, MD_BLOCK, 0, st>>>(dom_p2p_get_args(ctx, q.seq, 10ll * 100000000ll), ctx->scal.p, tmp.p);
+        double h[3] = {0, 0, 0};
+        HIPCHK(hipMemcpyAsync(h, tmp.p, sizeof h, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (h[2] != 0.0 || h[0] != 0.5 * R * (R + 1.0) || h[1] != (double)R) {
+            ok = 0;
+            why = "the rehearsal exchange did not deliver";
+        }
+        k_reset_viol<<<1, 1, 0, st>>>(ctx->scal.p);
+        all = agree(ok);
+    }
+    if (!all) {
+        if (d.rank == 0 && !(getenv("MDHIP_DOM_P2P") && getenv("MDHIP_DOM_P2P")[0] == '0'))
+            fprintf(stderr, "[mdhip] direct peer exchange not in use (%s); the slab step keeps its RCCL collectives\n",
+                    ok ? "a peer could not set it up" : why);
+        dom_p2p_teardown(ctx);
+        return;
+    }
+    double tsec = 60.0;
+    if (const char *e = getenv("MDHIP_P2P_TIMEOUT_S")) tsec = std::max(0.5, atof(e));
+    q.timeout = (long long)(tsec * 1e8);
+    if (getenv("MDHIP_DEBUG"))
+        fprintf(stderr, "[mdhip] rank %d: direct peer exchange ready (%d ranks, %lld records per plane, %.1f MB mailbox)\n", d.rank, R,
+                (long long)q.cap, 1e-6 * (double)p2p_bytes(R, q.cap));
+}
+
 struct DomAbortGuard {
     md_ctx *c;
     bool armed = true;
     ~DomAbortGuard()
     {
-        if (armed && c->dom.comm && g_rccl.CommAbort) {
+        if (!armed) return;
+        dom_p2p_poison(c);
+        if (c->dom.comm && g_rccl.CommAbort) {
             (void)g_rccl.CommAbort(c->dom.comm);
             c->dom.comm = nullptr;
         }
@@ -3155,16 +3404,69 @@ static int dom_run_window_fused(md_ctx *ctx, int64_t nsteps, double dt, int ense
     const size_t rs = rec_stride(ctx);
     const int post_grid = 1 + nblocks(std::max(n0s + n1s, 1));
     const int adopt_grid = nblocks(std::max(n0r + n1r, 1));
+    // direct peer exchange (agreed for this window by md_dom_run_window): the post stores into the peers' mailboxes, the
+    // adopt waits on this rank's own -- no collective in between
+    const bool p2p = d.p2p.on && d.p2p.window;
     auto post = [&](int t, int want, const double2 *rec, int what) {
+        P2pPut pa{};
+        double *o0 = sb[0], *o1 = sb[1];
+        if (p2p) {
+            d.p2p.seq += 1; // (one exchange = one post + one adopt; the adopt below uses the same number)
+            pa = dom_p2p_put_args(ctx, d.p2p.seq);
+            o0 = dom_p2p_send_plane(ctx, 0, d.p2p.seq);
+            o1 = dom_p2p_send_plane(ctx, 1, d.p2p.seq);
+        }
         k_dom_post<<<(what & 2) ? post_grid : 1, MD_BLOCK, 0, st>>>(ctx->n > 0 ? ctx->nblk : 0, ctx->partials.p, want, d.kuw_dev,
                                                                     ctx->scal.p, t, n0s, n1s, d.send_slot[0].p, d.send_slot[1].p,
-                                                                    rec, rs, shift_l, shift_r, sb[0], sb[1], what);
+                                                                    rec, rs, shift_l, shift_r, o0, o1, what, pa);
+    };
+    // ... and both halves in one launch when the whole grid is resident at once (md_domain.hpp k_dom_exchange)
+    const int xchg_grid = std::max(post_grid, adopt_grid);
+    const bool merged = p2p && xchg_grid <= 1024 && !getenv("MDHIP_DOM_P2P_SPLIT");
+    auto exchange = [&](int t, int want, double2 *rec, int finalize) {
+        d.p2p.seq += 1;
+        DomPostArgs pa{};
+        pa.nblk = ctx->n > 0 ? ctx->nblk : 0;
+        pa.partials = ctx->partials.p;
+        pa.kuw4 = d.kuw_dev;
+        pa.n0 = n0s;
+        pa.n1 = n1s;
+        pa.slot0 = d.send_slot[0].p;
+        pa.slot1 = d.send_slot[1].p;
+        pa.shift0 = shift_l;
+        pa.shift1 = shift_r;
+        pa.out0 = dom_p2p_send_plane(ctx, 0, d.p2p.seq);
+        pa.out1 = dom_p2p_send_plane(ctx, 1, d.p2p.seq);
+        pa.post_blocks = post_grid;
+        DomAdoptArgs aa{};
+        aa.n0 = n0r;
+        aa.n1 = n1r;
+        aa.xh_slot = d.xh_slot.p;
+        aa.in0 = dom_p2p_recv_plane(ctx, 0, d.p2p.seq);
+        aa.in1 = dom_p2p_recv_plane(ctx, 1, d.p2p.seq);
+        aa.planes = planes;
+        aa.pos = ctx->sb[ctx->cur].pos.p;
+        aa.nvt = nvt ? 1 : 0;
+        aa.nf = d.a_nf;
+        aa.term1 = d.a_term1;
+        aa.kt = ctx->d_kt.p;
+        aa.r1 = ctx->d_r1.p;
+        aa.r2 = ctx->d_r2.p;
+        aa.adopt_blocks = adopt_grid;
+        k_dom_exchange<<<xchg_grid, MD_BLOCK, 0, st>>>(pa, aa, rec, rec, rs, want, ctx->scal.p, t, finalize,
+                                                       dom_p2p_put_args(ctx, d.p2p.seq), dom_p2p_get_args(ctx, d.p2p.seq, d.p2p.timeout));
+    };
+    auto collectives = [&](bool sums) {
+        if (p2p) return;
+        if (sums)
+            g_rccl.check(g_rccl.AllReduce(d.kuw_dev, d.kuw_dev, 4, ncclFloat64, ncclSum, d.comm, st), "ncclAllReduce(K,U,W,viol)");
+        dom_exchange_records(ctx, sb, rb);
     };
     // MDHIP_DOM_OVERLAP=1: the record exchange overlaps the interior tiles.  Off by default: with ONE rank (the only
     // configuration this code has been timed in) the exchange is a local copy and the two extra stream hand-overs per step
     // cost more than it hides -- 0.231 against 0.199 ms/step, profiles/r02_slab_overlap_world1.txt; DESIGN.md section 6.
     const char *ov = getenv("MDHIP_DOM_OVERLAP");
-    const bool overlap = ov && ov[0] == '1' && d.n_tiles_i > 0 && d.n_tiles_b + d.n_tiles_i == ctx->nblk;
+    const bool overlap = !p2p && ov && ov[0] == '1' && d.n_tiles_i > 0 && d.n_tiles_b + d.n_tiles_i == ctx->nblk;
     if (overlap && !d.stream_i) {
         // (a priority of its own: the runtime then gives it a hardware queue of its own, so that the interior tiles
         // really run beside the boundary stream's kernels)
@@ -3175,17 +3477,28 @@ static int dom_run_window_fused(md_ctx *ctx, int64_t nsteps, double dt, int ense
         HIPCHK(hipEventCreateWithFlags(&d.ev_int, hipEventDisableTiming));
     }
     auto adopt = [&](int t, int want, double2 *rec, int finalize) {
-        k_dom_adopt<<<adopt_grid, MD_BLOCK, 0, st>>>(n0r, n1r, d.xh_slot.p, rb[0], rb[1], rec, rs, planes,
+        P2pGet ga{};
+        const double *i0 = rb[0], *i1 = rb[1];
+        if (p2p) {
+            ga = dom_p2p_get_args(ctx, d.p2p.seq, d.p2p.timeout);
+            i0 = dom_p2p_recv_plane(ctx, 0, d.p2p.seq);
+            i1 = dom_p2p_recv_plane(ctx, 1, d.p2p.seq);
+        }
+        k_dom_adopt<<<adopt_grid, MD_BLOCK, 0, st>>>(n0r, n1r, d.xh_slot.p, i0, i1, rec, rs, planes,
                                                      ctx->sb[ctx->cur].pos.p, d.kuw_dev, want, nvt ? 1 : 0, d.a_nf, d.a_term1,
-                                                     ctx->d_kt.p, ctx->d_r1.p, ctx->d_r2.p, ctx->scal.p, t, finalize);
+                                                     ctx->d_kt.p, ctx->d_r1.p, ctx->d_r2.p, ctx->scal.p, t, finalize, ga);
     };
     ctx->part = md_ctx::StepPart{}; // (a window that failed half-way may have left a part selected)
     // records of the state the window starts from: own particles from the arrays, the x-halo particles' from their owners
     FusedScope fscope{ctx};
     fused_enter(ctx, dt);
-    post(-1, 0, ctx->rec[0].p, 3); // (step -1 < every first_viol: packs; its sums are not used)
-    dom_exchange_records(ctx, sb, rb);
-    adopt(-1, 0, ctx->rec[0].p, 0);
+    if (merged) {
+        exchange(-1, 0, ctx->rec[0].p, 0);
+    } else {
+        post(-1, 0, ctx->rec[0].p, 3); // (step -1 < every first_viol: packs; its sums are not used)
+        collectives(false);
+        adopt(-1, 0, ctx->rec[0].p, 0);
+    }
     // MDHIP_DEBUG_DOM=1: wait after every stage and say so (finds the stage a rank is stuck in)
     const bool trace = getenv("MDHIP_DEBUG_DOM") != nullptr;
     int64_t t_now = 0;
@@ -3249,11 +3562,14 @@ static int dom_run_window_fused(md_ctx *ctx, int64_t nsteps, double dt, int ense
             }
             double2 *recB = ctx->rec[ctx->fz_a].p; // the set this step wrote
             stage("step");
-            post((int)t, want, recB, 3);
-            g_rccl.check(g_rccl.AllReduce(d.kuw_dev, d.kuw_dev, 4, ncclFloat64, ncclSum, d.comm, st), "ncclAllReduce(K,U,W,viol)");
-            stage("post + all-reduce");
-            dom_exchange_records(ctx, sb, rb);
-            adopt((int)t, want, recB, 1);
+            if (merged) {
+                exchange((int)t, want, recB, 1);
+            } else {
+                post((int)t, want, recB, 3);
+                stage("post");
+                collectives(true);
+                adopt((int)t, want, recB, 1);
+            }
             stage("exchange + adopt");
         }
         ctx->st_steps += 1;
@@ -3261,6 +3577,10 @@ static int dom_run_window_fused(md_ctx *ctx, int64_t nsteps, double dt, int ense
     }
     HIPCHK(hipGetLastError());
     Scalars h = read_scalars(ctx);
+    if (h.comm_error != 0)
+        throw HipError(h.comm_error == 2 ? "md_dom_run_window: a peer rank failed inside the window (direct peer exchange)"
+                                         : "md_dom_run_window: a peer rank did not deliver within the time limit (direct peer "
+                                           "exchange; MDHIP_P2P_TIMEOUT_S)");
     const int64_t fv = h.first_viol;
     const bool violated = fv < nsteps;
     if (violated) {
@@ -3306,7 +3626,8 @@ static int dom_run_window_fused(md_ctx *ctx, int64_t nsteps, double dt, int ense
         info[3] = ctx->prune_on ? 1.0 : 0.0;
         info[4] = ctx->skin;
         info[5] = ctx->prune_on ? ctx->inner_skin : 0.0;
-        info[6] = 1.0; // fused window: after a violation nothing of step first_viol is applied -- resume AT it
+        info[6] = p2p ? 2.0 : 1.0; // fused window (2: over the direct peer exchange): after a violation nothing of step
+                                   // first_viol is applied -- resume AT it
     }
     return 0;
 }
@@ -3326,12 +3647,20 @@ int md_dom_run_window(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, doub
         // the fused and the classic window exchange different things: every rank takes the fused one or none does
         // (a rank whose tiles did not fit the LDS at the last list build walks the generic rows)
         int32_t hf = dom_fused_available(ctx) ? 1 : 0;
+        if (hf && d.p2p.on) {
+            // 2: the direct peer exchange can carry this window (the record planes hold what the last build counted)
+            const int left = (d.rank + d.nranks - 1) % d.nranks, right = (d.rank + 1) % d.nranks;
+            if (d.nsend_halo[0] <= d.p2p.peer_cap[left] && d.nsend_halo[1] <= d.p2p.peer_cap[right] &&
+                d.nrecv_halo[0] <= d.p2p.cap && d.nrecv_halo[1] <= d.p2p.cap)
+                hf = 2;
+        }
         hipStream_t st = ctx->stream;
         HIPCHK(hipMemcpyAsync(d.own_flag.p, &hf, sizeof hf, hipMemcpyHostToDevice, st));
         g_rccl.check(g_rccl.AllReduce(d.own_flag.p, d.own_flag.p, 1, ncclInt32, ncclMin, d.comm, st), "ncclAllReduce(path)");
         HIPCHK(hipMemcpyAsync(&hf, d.own_flag.p, sizeof hf, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
-        ctx->last_run_fused = hf == 1;
+        ctx->last_run_fused = hf >= 1;
+        d.p2p.window = hf == 2;
     }
     if (getenv("MDHIP_DEBUG"))
         fprintf(stderr, "[mdhip] rank %d md_dom_run_window: %lld steps fused=%d (tiles=%d virtual_ghosts=%d allow=%d) since build %lld inner_valid=%d\n",

@@ -582,6 +582,8 @@ class DomainDevice:
             window(wlen, dt, ensemble, tau, nf, arrs, nvt, ends_run, Lp, fv, uwk, info)
             self.windows = getattr(self, "windows", 0) + 1
             self.fused_windows = getattr(self, "fused_windows", 0) + (1 if info[6] > 0.0 else 0)
+            # info[6] == 2: the window's records and sums travelled as one-sided stores into the peers' mailboxes
+            self.direct_windows = getattr(self, "direct_windows", 0) + (1 if info[6] > 1.0 else 0)
             pruning = info[3] > 0.0
             self._skins = (info[4], info[5])
             if fv.value < wlen:

@@ -71,7 +71,7 @@ def main():
         runner = {"0": d.run, "1": d.run_async, "native": d.run_native}[os.environ.get("DOM_ASYNC", "0")]
         Ue, We, Ke = runner(nsteps, dt, ens, 0.1, nf, kt, r1, r2)
         X, V, F, IM = d.gather_global()
-        stats = (d.builds, d.violations, d.counts(), d.stats()["prunes"], (getattr(d, "fused_windows", 0), getattr(d, "windows", 0)))
+        stats = (d.builds, d.violations, d.counts(), d.stats()["prunes"], (getattr(d, "fused_windows", 0), getattr(d, "windows", 0), getattr(d, "direct_windows", 0)))
     ok = True
     if rank == 0:
         from oracle import oracle as orc
@@ -98,6 +98,10 @@ def main():
             # md_dom_run_window took the fused step: in every window, unless some rank's tiles stopped fitting the LDS
             # at a list build (per-particle diameters: 32-byte records) and all ranks went on with the classic sequence
             ok &= stats[4][0] >= 1 and (stats[4][0] == stats[4][1] or os.environ.get("DOM_POLY", "0") == "1")
+        if os.environ.get("DOM_EXPECT_DIRECT", "") == "1":
+            ok &= stats[4][2] >= 1 and stats[4][2] == stats[4][0]      # every fused window used the direct peer exchange
+        if os.environ.get("DOM_EXPECT_DIRECT", "") == "0":
+            ok &= stats[4][2] == 0
         if os.environ.get("DOM_EXPECT_VIOL", "0") == "1":
             ok &= stats[1] >= 1      # some window was cut short by a displacement violation
     flag = [ok]

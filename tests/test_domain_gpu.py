@@ -77,6 +77,12 @@ def _launch(nproc, env_extra, port):
     # MDHIP_DOM_OVERLAP=1: boundary tiles first, the interior tiles on a second stream while the records travel
     # (110592 particles: slabs of 24.9, wide enough for tiles that touch neither face)
     (2, 1, "device", "shim-native-prune-big-overlap"), (1, 1, "", "nccl-native-prune-overlap"),
+    # the native modes above run the fused window over the DIRECT PEER EXCHANGE (one-sided stores into the peers'
+    # mailboxes, csrc/md_domain.hpp; the worker requires it in every fused window); with MDHIP_DOM_P2P=0 the same
+    # windows keep their two collectives per step
+    (2, 1, "device", "shim-native-prune-rccl"), (3, 0, "device", "shim-native-rccl"), (1, 1, "", "nccl-native-prune-rccl"),
+    # ... and MDHIP_DOM_P2P_SPLIT=1 keeps the direct exchange's post and adopt in two launches (the form large faces use)
+    (3, 1, "device", "shim-native-prune-split"),
 ])
 def test_slab_decomposition_matches_single_gpu(nproc, nvt, stage, mode):
     # N=8000 -> L=20.7: 2 slabs of 10.4, 3 slabs of 6.9 (>= 2 cells each); kT=2 and dt=0.002 make
@@ -98,9 +104,17 @@ def test_slab_decomposition_matches_single_gpu(nproc, nvt, stage, mode):
                                                                 "shim-native-prune-cfg4": 560, "shim-native-prune-poly": 600,
                                                                 "shim-native-poly": 640, "shim-native-prune-classic": 680,
                                                                 "nccl-native-prune-classic": 720, "shim-native-prune-big-overlap": 760,
-                                                                "nccl-native-prune-overlap": 840}[mode]
+                                                                "nccl-native-prune-overlap": 840, "shim-native-prune-rccl": 880,
+                                                                "shim-native-rccl": 920, "nccl-native-prune-rccl": 960,
+                                                                "shim-native-prune-split": 1000}[mode]
     if mode.endswith("overlap"):
         env["MDHIP_DEBUG"] = "1"
+    if "native" in mode:
+        direct = not (mode.endswith("overlap") or mode.endswith("rccl") or mode.endswith("classic"))
+        env["MDHIP_DOM_P2P"] = "1" if direct else "0"      # (the overlapped window is built on the collectives)
+        env["DOM_EXPECT_DIRECT"] = "1" if direct else "0"
+        if mode.endswith("split"):
+            env["MDHIP_DOM_P2P_SPLIT"] = "1"
     err = _launch(nproc, env, port)
     if mode.endswith("overlap"):
         # the split launches really ran: some rank had interior tiles after a list build
@@ -117,21 +131,24 @@ def test_violation_inside_a_fused_slab_window(nproc, nvt):
     single-handle trajectory.  The worker requires violations >= 1 and the fused window form in every window."""
     env = {"DOM_KT": "2.0", "DOM_STEPS": "120", "DOM_NVT": str(nvt), "MDHIP_DOM_STAGE": "device", "DOM_ASYNC": "native",
            "MDHIP_RCCL_PATH": _build_shim(), "DOM_PRUNE": "1", "DOM_POLY": "0", "DOM_ELONG": "0", "DOM_N": "8000",
-           "DOM_BACKEND": "gloo", "DOM_SAFETY": "1.6", "DOM_EXPECT_VIOL": "1"}
+           "DOM_BACKEND": "gloo", "DOM_SAFETY": "1.6", "DOM_EXPECT_VIOL": "1", "DOM_EXPECT_DIRECT": "1"}
     _launch(nproc, env, 29931 + nproc)
 
 
-def test_a_failing_rank_releases_its_peer():
+@pytest.mark.parametrize("direct", [1, 0])
+def test_a_failing_rank_releases_its_peer(direct):
     """MDHIP_DOM_FAIL=1:7 -- rank 1 throws inside its third-or-so window at step 7.  Its DomAbortGuard aborts the
-    communicator; rank 0, blocked in (or arriving at) the step's collective, must come back with an error promptly
+    communicator (and, over the direct peer exchange, poisons the flags it owns in its peers' mailboxes); rank 0, blocked
+    in (or arriving at) the step's collective or waiting on its mailbox, must come back with an error promptly
     instead of waiting for the watchdog.  Both ranks exit non-zero; the job ends well inside the watchdog's 240 s."""
     import time
     env = dict(os.environ)
+    env["MDHIP_DOM_P2P"] = str(direct)
     env.update({"DOM_KT": "2.0", "DOM_STEPS": "60", "DOM_NVT": "1", "MDHIP_DOM_STAGE": "device", "DOM_ASYNC": "native",
                 "MDHIP_RCCL_PATH": _build_shim(), "DOM_PRUNE": "1", "DOM_N": "8000", "DOM_BACKEND": "gloo",
                 "MDHIP_DOM_FAIL": "1:2", "OMP_NUM_THREADS": "2", "DOM_WATCHDOG": "240"})
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-           "--master-port", "29957", os.path.join(ROOT, "tests", "domain_gpu_worker.py")]
+           "--master-port", str(29957 + direct), os.path.join(ROOT, "tests", "domain_gpu_worker.py")]
     t0 = time.time()
     p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
     try:
@@ -145,7 +162,7 @@ def test_a_failing_rank_releases_its_peer():
     assert p.returncode != 0
     assert "injected failure" in err, "rank 1 did not fail where asked"
     # the peer's error names the collective that came back with an error (not a watchdog dump)
-    assert "nccl" in err.lower() and "Timeout" not in err and "dump_traceback" not in err
+    assert ("nccl" in err.lower() or "peer rank failed" in err) and "Timeout" not in err and "dump_traceback" not in err
     assert took < 150
 
 
