@@ -445,6 +445,7 @@ def main():
                 f"BASELINE configs[2]: N={n_arg} monodisperse LJ 3D rho=0.897 r_cut=2.5 dt=0.001 "
                 f"{'NVT Bussi tau=0.1 kT=1.4737' if nvt else 'NVE'}"
                 + (", per GPU" if scaling == "weak" else f", {total_particles} particles in total"))
+    direct_windows = int(getattr(dev, "direct_windows", 0)) if use_domain else 0
     out = {
         "metric": "particle-steps/sec + achieved HBM GB/s, 1M LJ particles rho=0.897, 1/2/4/8 GPUs",
         "value": value,
@@ -468,7 +469,10 @@ def main():
                 f"({dist.get_backend()}), step loop: {loop}"),
             "step_loop": ("classic (k_kickdrift, k_force_tile, k_finalize)" if not fused else
                           "fused (k_step_tile: one launch per step + k_finalize)" if not use_domain else
-                          "fused slab step (k_step_tile, k_dom_post, all-reduce, record exchange, k_dom_adopt)"),
+                          ("fused slab step over the direct peer exchange (k_step_tile, k_dom_exchange: one-sided stores into the "
+                           "peers' mailboxes, no collective)" if direct_windows > 0 else
+                           "fused slab step (k_step_tile, k_dom_post, all-reduce, record exchange, k_dom_adopt)")),
+            "direct_exchange_windows": direct_windows if use_domain else None,
             "skin": a.skin if a.skin is not None else (0.6 if (not use_domain or st1["prunes"] > 0) else 0.4),
             "rebuilds_in_timed_region": st1["rebuilds"] - st0["rebuilds"],
             "global_particles": total_particles,

@@ -270,14 +270,23 @@ int md_dom_run_window(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, doub
                       const double *r1, const double *r2, int report_last, int apply_pending_scale,
                       int64_t prune_interval, int32_t *first_viol, double *uwk, double *info /* [7] or NULL */);
 /* On tiled handles md_dom_run_window runs the FUSED step (csrc/md_domain.hpp: one step kernel + two small launches and two
- * collectives per step; what travels is the boundary particles' state records).  Then info[6] = 1 and, after a violation,
+ * collectives per step; what travels is the boundary particles' state records).
+ * DIRECT PEER EXCHANGE: md_dom_comm_init also gives every rank a mailbox in fine-grained device memory, shares it with
+ * the other ranks (hipIpc handles, carried by the communicator) and rehearses one exchange; if every rank succeeds,
+ * a fused window moves its sums and records as ONE-SIDED STORES into the peers' mailboxes (over xGMI between GPUs) and
+ * waits on flags in its own -- no collective call per step, one small launch (k_dom_exchange) instead of two launches
+ * and two collectives; info[6] = 2.  Anything that prevents it on any rank (no peer access, MDHIP_DOM_P2P=0, more
+ * than 16 ranks, a face with more records than a mailbox plane) leaves all ranks on the collectives.  Waits are bounded
+ * (MDHIP_P2P_TIMEOUT_S, default 60 s): a peer that never delivers is an error, not a hang.
+ * With the fused step info[6] >= 1 and, after a violation,
  * the state returned is that of the last complete step first_viol - 1: the caller refreshes the rows and resumes AT step
  * first_viol (no md_dom_forces call).  info[6] = 0: the classic sequence ran -- the violating step's drift is applied and
  * md_dom_forces completes it.
  * A fused window refreshes the x-halo particles' state RECORDS, not their coordinates: until the next list build (or a
  * classic step's exchange) md_dom_forces refuses to run -- it would read neighbour coordinates as of the last build.
  * A failure of one rank inside a window aborts the communicator (its peers' collectives return an error instead of
- * waiting); the handle needs md_dom_comm_init again.  Any call that fails inside a fused step loop (md_run,
+ * waiting) and poisons the flags that rank owns in its peers' mailboxes (their waits end at once with an error); the
+ * handle needs md_dom_comm_init again.  Any call that fails inside a fused step loop (md_run,
  * md_dom_run_window) leaves the handle's particle state incomplete: later calls that read it fail until md_upload /
  * md_dom_upload provides x, v and f again.                                                                        */
 /* Inner rows (see md_set_inner_skin) on a slab handle.  Every rank must prune at the same steps, so the caller

@@ -12,7 +12,9 @@ python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_n1_d
 echo "bench 20 done"
 python bench.py --gpus 1 --config 4 --steps 100 --warmup 20 --no-cpu-baseline > $O/bench_config4_n1.json 2> $O/bench_config4_n1.err
 echo "bench config4 done"
-MDHIP_BENCH_DOMAIN=1 python bench.py --steps 200 --warmup 50 --no-cpu-baseline > $O/bench_slab_path_world1_rccl.json 2> $O/bench_slab.err || echo "slab path bench failed"
+# the slab machinery with one rank (its own neighbour): over the direct peer exchange (the default) and over RCCL
+MDHIP_BENCH_DOMAIN=1 python bench.py --steps 200 --warmup 50 --no-cpu-baseline > $O/bench_slab_path_world1_direct.json 2> $O/bench_slab.err || echo "slab path bench failed"
+MDHIP_DOM_P2P=0 MDHIP_BENCH_DOMAIN=1 python bench.py --steps 200 --warmup 50 --no-cpu-baseline > $O/bench_slab_path_world1_rccl.json 2> $O/bench_slab_rccl.err || echo "slab path bench (rccl) failed"
 echo "bench slab done"
 # energies every step (the reference's frequency = 1): one md_run call per step, the last step of each with U and W
 python bench.py --steps 200 --warmup 50 --frequency 1 --no-cpu-baseline > $O/bench_n1_frequency1.json 2> $O/bench_f1.err
