@@ -6,6 +6,7 @@
 // ensemble_step!.  See md_kernels.hpp for the kernels and DESIGN.md for the data layout.
 #include <cstring>
 #include <cstdlib>
+#include <unistd.h>
 
 #include "md_kernels.hpp"
 #include "md_domain.hpp"
@@ -3509,12 +3510,21 @@ static int dom_run_window_fused(md_ctx *ctx, int64_t nsteps, double dt, int ense
     };
     // MDHIP_DOM_FAIL="rank:step": this rank fails inside the window at that step (tests: its peers must error out through
     // the aborted communicator, not wait for a collective that never comes)
+    // "rank:step:seconds": that rank stalls for so long instead (host sleep with the device idle): its peers' bounded
+    // waits must end with the time-limit error (MDHIP_P2P_TIMEOUT_S), and the late rank must find the poison they left
     int fail_rank = -1, fail_step = -1;
-    if (const char *e = getenv("MDHIP_DOM_FAIL")) (void)sscanf(e, "%d:%d", &fail_rank, &fail_step);
+    double fail_sleep = 0.0;
+    if (const char *e = getenv("MDHIP_DOM_FAIL")) (void)sscanf(e, "%d:%d:%lf", &fail_rank, &fail_step, &fail_sleep);
     if (nsteps > 0) d.xhalo_pos_stale = true;
     for (int64_t t = 0; t < nsteps; ++t) {
         t_now = t;
-        if (d.rank == fail_rank && t == fail_step) throw HipError("md_dom_run_window: injected failure (MDHIP_DOM_FAIL)");
+        if (d.rank == fail_rank && t == fail_step) {
+            if (!(fail_sleep > 0.0)) throw HipError("md_dom_run_window: injected failure (MDHIP_DOM_FAIL)");
+            HIPCHK(hipStreamSynchronize(st));
+            fprintf(stderr, "[mdhip] rank %d: injected stall of %.1f s (MDHIP_DOM_FAIL)\n", d.rank, fail_sleep);
+            usleep((useconds_t)(fail_sleep * 1e6));
+            fail_rank = -1; // (once)
+        }
         const int want = (report_last && t == nsteps - 1) ? 1 : 0;
         // inner rows: the schedule (identical on every rank) is the caller's prune interval
         if (ctx->prune_on && ctx->inner_valid && d.w_prune_interval > 0 && ctx->steps_since_prune >= d.w_prune_interval)

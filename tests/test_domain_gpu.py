@@ -166,6 +166,34 @@ def test_a_failing_rank_releases_its_peer(direct):
     assert took < 150
 
 
+def test_a_stalled_rank_ends_its_peers_wait():
+    """MDHIP_DOM_FAIL=1:2:8 -- rank 1 stalls for 8 s inside a window (device idle).  Over the direct peer exchange rank 0
+    waits on its mailbox, bounded by MDHIP_P2P_TIMEOUT_S = 2: it must come back with the time-limit error, not hang until
+    rank 1 wakes up or the watchdog fires; its abort poisons rank 1's flags, so the late rank errors out as well."""
+    import time
+    env = dict(os.environ)
+    env.update({"DOM_KT": "2.0", "DOM_STEPS": "60", "DOM_NVT": "1", "MDHIP_DOM_STAGE": "device", "DOM_ASYNC": "native",
+                "MDHIP_RCCL_PATH": _build_shim(), "DOM_PRUNE": "1", "DOM_N": "8000", "DOM_BACKEND": "gloo",
+                "MDHIP_DOM_FAIL": "1:2:8", "MDHIP_P2P_TIMEOUT_S": "2", "MDHIP_DOM_P2P": "1", "OMP_NUM_THREADS": "2",
+                "DOM_WATCHDOG": "240"})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29961", os.path.join(ROOT, "tests", "domain_gpu_worker.py")]
+    t0 = time.time()
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        out, err = p.communicate(timeout=200)
+    except subprocess.TimeoutExpired:
+        os.killpg(p.pid, signal.SIGKILL)
+        p.communicate()
+        raise AssertionError("a rank kept waiting for its stalled peer")
+    took = time.time() - t0
+    sys.stderr.write(err[-2500:])
+    assert p.returncode != 0
+    assert "injected stall" in err, "rank 1 did not stall where asked"
+    assert "did not deliver within the time limit" in err and "dump_traceback" not in err
+    assert took < 150
+
+
 def test_slab_half_million_particles_per_rank():
     """BASELINE configs[3]'s per-rank load (4,194,304 / 8 = 524,288 owned particles per GPU): two ranks, the
     2^20-particle cube of the metric cut into two slabs of 52.7 (as bench.py --gpus 2 --scaling strong does), native
