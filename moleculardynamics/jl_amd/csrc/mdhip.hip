@@ -3161,10 +3161,7 @@ static void dom_p2p_setup(md_ctx *ctx)
             ok = 0;
             why = "MDHIP_DOM_P2P=0";
         }
-    if (d.nranks > MD_P2P_MAXR) {
-        ok = 0;
-        why = "more ranks than mailbox slots";
-    }
+    if (d.nranks > MD_P2P_MAXR) return; // (every rank sees the same count: nothing to agree on)
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
     const int R = d.nranks;
     q.cap = ctx->ncap;

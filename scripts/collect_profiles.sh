@@ -3,7 +3,7 @@
 # copies the round's evidence set (scripts/profile_round.sh) into profiles/<tag>_* and prints the headline numbers
 tag=${1:-rXX}
 P=gpurun_out/prof_$tag
-for pair in "bench_n1.json bench_n1.json" "bench_n1_driver_cmd.json bench_n1_steps20_warmup5.json" "bench_config4_n1.json bench_config4_n1.json" "bench_slab_path_world1_rccl.json bench_slab_path_world1_rccl.json" "bench_slab_path_world1_direct.json bench_slab_path_world1_direct.json" "bench_n1_frequency1.json bench_n1_frequency1.json" "bench_gpus2_launcher_gloo_one_gpu.json bench_gpus2_launcher_gloo_one_gpu.json"; do
+for pair in "bench_n1.json bench_n1.json" "bench_n1_driver_cmd.json bench_n1_steps20_warmup5.json" "bench_config4_n1.json bench_config4_n1.json" "bench_slab_path_world1_rccl.json bench_slab_path_world1_rccl.json" "bench_slab_path_world1_direct.json bench_slab_path_world1_direct.json" "bench_n1_frequency1.json bench_n1_frequency1.json" "bench_gpus2_launcher_gloo_one_gpu.json bench_gpus2_launcher_gloo_one_gpu.json" "bench_gpus2_native_direct_shim_one_gpu.json bench_gpus2_native_direct_shim_one_gpu.json"; do
   set -- $pair
   grep "^{" $P/$1 | tail -1 > profiles/${tag}_$2
   python3 - profiles/${tag}_$2 <<'PY'

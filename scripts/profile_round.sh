@@ -22,6 +22,10 @@ echo "bench frequency 1 done"
 # bench.py --gpus 2 launches its two ranks itself (both on this box's one GPU: gloo carries the exchanges) -- the
 # launcher's plumbing, not a scaling number
 MDHIP_BENCH_BACKEND=gloo python3 bench.py --gpus 2 --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_gpus2_launcher_gloo_one_gpu.json 2> $O/bench_g2.err || echo "2-rank launcher run failed"
+# ... and the NATIVE two-rank loop over the direct peer exchange, both ranks on this one GPU (list-build collectives through
+# tests/shim/libncclshim.so): 2 x 2^20 particles, the mailboxes mapped between the two processes -- functional, not a scaling number
+hipcc -O2 -fPIC -shared --offload-arch=gfx950 -o tests/shim/libncclshim.so tests/shim/nccl_shim.cpp -lrt
+MDHIP_BENCH_BACKEND=gloo MDHIP_DOM_LOOP=native MDHIP_RCCL_PATH=$R/tests/shim/libncclshim.so python3 bench.py --gpus 2 --steps 40 --warmup 10 --no-cpu-baseline > $O/bench_gpus2_native_direct_shim_one_gpu.json 2> $O/bench_g2n.err || echo "2-rank native run failed"
 echo "bench --gpus 2 done"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks -- python3 $R/bench.py --no-cpu-baseline --steps 400 --warmup 50 > $O/ks.log 2>&1
