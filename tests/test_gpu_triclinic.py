@@ -77,6 +77,14 @@ def test_triclinic_cells_match_the_oracle(oracle, name, n, cutoff, skin):
     assert abs(U2 - ref["U"]) <= 1e-9 * abs(ref["U"]) and abs(K2 - ref["K"]) <= 1e-9 * abs(ref["K"])
 
 
+@pytest.mark.parametrize("switch", ["MDHIP_NO_FUSED_STEP", "MDHIP_NO_TILES", "MDHIP_NO_FUSED_BUILD"])
+def test_triclinic_on_the_other_code_paths(oracle, monkeypatch, switch):
+    """The classic three-kernel loop, the generic (global-gather) force kernel with real ghost copies, and the two-kernel
+    list build handle a general cell too (the switches are read when the handle is created)."""
+    monkeypatch.setenv(switch, "1")
+    test_triclinic_cells_match_the_oracle(oracle, "full_tilt", 1600, 2.5, 0.3)
+
+
 def test_diagonal_matrix_as_general_cell_is_the_orthorhombic_path(oracle):
     """A diagonal matrix never enters the general-cell code (md_create classifies it): same stats, same bits."""
     from moleculardynamics.jl_amd import MDDevice
