@@ -3405,11 +3405,12 @@ static int dom_run_window_fused(md_ctx *ctx, int64_t nsteps, double dt, int ense
     // direct peer exchange (agreed for this window by md_dom_run_window): the post stores into the peers' mailboxes, the
     // adopt waits on this rank's own -- no collective in between
     const bool p2p = d.p2p.on && d.p2p.window;
-    auto post = [&](int t, int want, const double2 *rec, int what) {
+    auto post = [&](int t, int want, const double2 *rec, int what, bool new_exchange = true) {
         P2pPut pa{};
         double *o0 = sb[0], *o1 = sb[1];
         if (p2p) {
-            d.p2p.seq += 1; // (one exchange = one post + one adopt; the adopt below uses the same number)
+            // (one exchange = its posts -- records and sums may go out in two launches -- and one adopt, all under one number)
+            if (new_exchange) d.p2p.seq += 1;
             pa = dom_p2p_put_args(ctx, d.p2p.seq);
             o0 = dom_p2p_send_plane(ctx, 0, d.p2p.seq);
             o1 = dom_p2p_send_plane(ctx, 1, d.p2p.seq);
@@ -3464,7 +3465,7 @@ static int dom_run_window_fused(md_ctx *ctx, int64_t nsteps, double dt, int ense
     // configuration this code has been timed in) the exchange is a local copy and the two extra stream hand-overs per step
     // cost more than it hides -- 0.231 against 0.199 ms/step, profiles/r02_slab_overlap_world1.txt; DESIGN.md section 6.
     const char *ov = getenv("MDHIP_DOM_OVERLAP");
-    const bool overlap = !p2p && ov && ov[0] == '1' && d.n_tiles_i > 0 && d.n_tiles_b + d.n_tiles_i == ctx->nblk;
+    const bool overlap = ov && ov[0] == '1' && d.n_tiles_i > 0 && d.n_tiles_b + d.n_tiles_i == ctx->nblk;
     if (overlap && !d.stream_i) {
         // (a priority of its own: the runtime then gives it a hardware queue of its own, so that the interior tiles
         // really run beside the boundary stream's kernels)
@@ -3549,12 +3550,13 @@ static int dom_run_window_fused(md_ctx *ctx, int64_t nsteps, double dt, int ense
             HIPCHK(hipEventRecord(d.ev_int, d.stream_i));
             double2 *recB = ctx->rec[ctx->fz_a].p; // the set this step wrote
             post((int)t, want, recB, 2);
-            dom_exchange_records(ctx, sb, rb);
+            if (!p2p) dom_exchange_records(ctx, sb, rb);
             HIPCHK(hipStreamWaitEvent(st, d.ev_int, 0));
             prof_end(ctx); // (boundary tiles + pack + exchange, or the interior tiles: whichever took longer)
             stage("step + exchange");
-            post((int)t, want, recB, 1);
-            g_rccl.check(g_rccl.AllReduce(d.kuw_dev, d.kuw_dev, 4, ncclFloat64, ncclSum, d.comm, st), "ncclAllReduce(K,U,W,viol)");
+            post((int)t, want, recB, 1, false);
+            if (!p2p)
+                g_rccl.check(g_rccl.AllReduce(d.kuw_dev, d.kuw_dev, 4, ncclFloat64, ncclSum, d.comm, st), "ncclAllReduce(K,U,W,viol)");
             adopt((int)t, want, recB, 1);
             stage("sums + all-reduce + adopt");
         } else {

@@ -83,6 +83,9 @@ def _launch(nproc, env_extra, port):
     (2, 1, "device", "shim-native-prune-rccl"), (3, 0, "device", "shim-native-rccl"), (1, 1, "", "nccl-native-prune-rccl"),
     # ... and MDHIP_DOM_P2P_SPLIT=1 keeps the direct exchange's post and adopt in two launches (the form large faces use)
     (3, 1, "device", "shim-native-prune-split"),
+    # ... and the overlapped window over the direct exchange: the records go out (stream-ordered stores) while the interior
+    # tiles run on their own stream
+    (2, 1, "device", "shim-native-prune-big-overlap-direct"),
 ])
 def test_slab_decomposition_matches_single_gpu(nproc, nvt, stage, mode):
     # N=8000 -> L=20.7: 2 slabs of 10.4, 3 slabs of 6.9 (>= 2 cells each); kT=2 and dt=0.002 make
@@ -93,7 +96,7 @@ def test_slab_decomposition_matches_single_gpu(nproc, nvt, stage, mode):
            "MDHIP_RCCL_PATH": _build_shim() if mode.startswith("shim") else "",
            "DOM_PRUNE": "1" if "prune" in mode else "0", "DOM_STEPS": "120" if "prune" in mode else "60",
            "MDHIP_NO_FUSED_STEP": "1" if mode.endswith("classic") else "0",
-           "MDHIP_DOM_OVERLAP": "1" if mode.endswith("overlap") else "0",
+           "MDHIP_DOM_OVERLAP": "1" if "overlap" in mode else "0",
            "DOM_POLY": "1" if mode.endswith("poly") else "0", "DOM_ELONG": "1" if mode.endswith("elong") else "0",
            "DOM_N": "8232" if mode.endswith("elong") else ("27000" if "cfg4" in mode else ("110592" if "big" in mode else "8000")),   # 8232 = 2 * 4116 = 3 * 2744
            "DOM_BACKEND": "nccl" if mode.startswith("nccl") else "gloo"}
@@ -106,8 +109,9 @@ def test_slab_decomposition_matches_single_gpu(nproc, nvt, stage, mode):
                                                                 "nccl-native-prune-classic": 720, "shim-native-prune-big-overlap": 760,
                                                                 "nccl-native-prune-overlap": 840, "shim-native-prune-rccl": 880,
                                                                 "shim-native-rccl": 920, "nccl-native-prune-rccl": 960,
-                                                                "shim-native-prune-split": 1000}[mode]
-    if mode.endswith("overlap"):
+                                                                "shim-native-prune-split": 1000,
+                                                                "shim-native-prune-big-overlap-direct": 1040}[mode]
+    if "overlap" in mode:
         env["MDHIP_DEBUG"] = "1"
     if "native" in mode:
         direct = not (mode.endswith("overlap") or mode.endswith("rccl") or mode.endswith("classic"))
@@ -116,7 +120,7 @@ def test_slab_decomposition_matches_single_gpu(nproc, nvt, stage, mode):
         if mode.endswith("split"):
             env["MDHIP_DOM_P2P_SPLIT"] = "1"
     err = _launch(nproc, env, port)
-    if mode.endswith("overlap"):
+    if "overlap" in mode:
         # the split launches really ran: some rank had interior tiles after a list build
         import re
         counts = [int(m) for m in re.findall(r"slab tiles: \d+ boundary, (\d+) interior", err)]
