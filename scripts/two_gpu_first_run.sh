@@ -35,7 +35,6 @@ done
 python3 bench.py --gpus 1 --steps 200 --warmup 50 --no-cpu-baseline > $O/bench_n1.json 2> $O/bench_n1.err
 grep "^{" $O/bench_n1.json | tail -1 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('== 1 GPU: value %.4g ms/step %.4f'%(d['value'], d['ms_per_step']))" | tee -a $O/log.txt
 
-# 4. one window's timeline: how long k_dom_exchange waits for the neighbour's records beside the step kernel
-cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --gpus $N --steps 60 --warmup 20 --no-cpu-baseline > $O/trace.log 2>&1
+# (no rocprofv3 pass here: the N-rank bench starts its ranks as child processes, and a profiler-preloaded parent must not
+# exec; per-kernel times of a multi-rank run come from MDHIP_DOM_TIMING=1 and the bench line's step_breakdown_ms)
 echo "done: $O/log.txt"
