@@ -110,7 +110,11 @@ int md_neighbor_pairs(md_ctx *ctx, int32_t *pairs, int64_t cap, int64_t *count);
  * s (r1 = randn, r2 = sum_noises(nf-1), src/thermostat.jl:1-18,32-33): the RNG stays on the
  * host.  nf is SimulationState.nf = d*(N-1) (src/initialization.jl:124).
  * If uwk != NULL it receives {U, W, K} of the LAST step (potential energy, virial, kinetic
- * energy after the thermostat) -- what the thermo line of src/simulation.jl:118-136 needs. */
+ * energy after the thermostat) -- what the thermo line of src/simulation.jl:118-136 needs.
+ * Stated deviation: the reference rebuilds its cells every step and keeps stepping (and printing NaN / garbage) when a
+ * system blows up; md_run follows its Verlet rows and returns an error when a particle moves more than half the list skin
+ * in ONE step three times over at the same step (no list can follow that).  Non-finite coordinates that do not trip the
+ * displacement test are carried along as the reference carries them.                                                  */
 int md_run(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, double tau, double nf, const double *ktemp,
            const double *r1, const double *r2, double *uwk);
 

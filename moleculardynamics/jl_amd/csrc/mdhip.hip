@@ -1879,6 +1879,7 @@ int md_run(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, double tau, dou
             return std::sqrt(d0sq);
         };
         int s = 0;
+        int redo_step = -1, redo_count = 0; // the same step violated again right after its list build
         std::vector<int> prune_steps;
         while (s < (int)nsteps) {
             const bool pruning = ctx->prune_on;
@@ -1889,7 +1890,10 @@ int md_run(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, double tau, dou
                 R = ctx->steps_since_build + 4; // a short first window, measured at its end
                 L = 4;
             } else {
-                double r_out = std::max(ctx->d1_rate, 1e-12);
+                // (a system that has blown up measures NaN or inf displacements: plan the shortest windows -- the reference
+                // goes on producing NaNs in that case, it does not stop; an unguarded NaN here ended in a SIGFPE of the
+                // integer divisions below)
+                double r_out = std::isfinite(ctx->d1_rate) ? std::max(ctx->d1_rate, 1e-12) : 1e300;
                 double Rf = std::floor(ctx->safety * 0.5 * ctx->skin / r_out) + 1.0;
                 double Lf = std::floor(ctx->safety * 0.5 * ctx->inner_skin / (1.1 * r_out)) + 1.0;
                 int64_t Rmax = (int64_t)std::min(std::max(Rf, 2.0), 4096.0);
@@ -1949,6 +1953,19 @@ int md_run(md_ctx *ctx, int64_t nsteps, double dt, int ensemble, double tau, dou
                 // (fused loop: the step launched again after the previous violation can flag ITSELF -- its prune
                 // found a tile whose inner halo does not fit -- which is seen only now: m == s - 1, nothing after it ran)
                 if (m < s - 1 || (m < s && !fused)) throw HipError("internal: stale displacement-violation index");
+                // The step launched again after a list build flags itself again: a particle moves more than half the
+                // skin in ONE step (the rows of the fused loop are one step old when they are used).  Building again
+                // cannot help and the loop would never advance: the run is beyond what a Verlet list can follow -- in
+                // practice a system that has blown up.  (The reference rebuilds its cells every step and goes on printing
+                // garbage; this is a stated deviation: an error instead.)
+                if (m == redo_step) {
+                    if (++redo_count >= 3)
+                        throw HipError("md_run: a particle moves more than half the list skin in a single step (time step too "
+                                       "large for this skin, or the system has blown up)");
+                } else {
+                    redo_step = m;
+                    redo_count = 0;
+                }
                 ctx->st_viol++;
                 bool m_was_prune = (h.halo_overflow & 16) != 0;
                 for (int p : prune_steps)

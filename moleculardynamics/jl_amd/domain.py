@@ -508,7 +508,7 @@ class DomainDevice:
     def _plan(self, skin, inner):
         """Rebuild interval R and prune interval L from the measured growth rate of the largest displacement
         (the planner of md_run, csrc/mdhip.hip; a slab list build costs ~15 prune steps)."""
-        r = max(self._rate, 1e-12)
+        r = max(self._rate, 1e-12) if np.isfinite(self._rate) else 1e300      # (blown-up system: shortest windows)
         rmax = int(min(max(np.floor(self._safety * 0.5 * skin / r) + 1.0, 2.0), 4096.0))
         lmax = int(min(max(np.floor(self._safety * 0.5 * inner / (1.1 * r)) + 1.0, 2.0), 4096.0))
         best, R = 1e300, rmax
@@ -567,6 +567,7 @@ class DomainDevice:
             self._pruning = bool(getattr(self, "_prune_req", False))
             self._skins = (0.0, 0.0)
         s = 0
+        stuck = 0
         while s < nsteps:
             R, Lp = None, 0
             if self._pruning:
@@ -616,6 +617,15 @@ class DomainDevice:
                     self._chk(L.md_dom_invalidate_inner(h))
                     self.steps_since_build = ssb
                 if fused:
+                    # (the same step violated again right after its rows were refreshed: some particle moves more than
+                    # half the skin in one step -- refreshing again cannot help, the loop would never advance)
+                    if m == 0:
+                        stuck += 1
+                        if stuck >= 3:
+                            raise MdhipError("run_native: a particle moves more than half the list skin in a single step "
+                                             "(time step too large for this skin, or the system has blown up)")
+                    else:
+                        stuck = 0
                     s = g
                     self._pruning = pruning
                     continue
@@ -631,6 +641,7 @@ class DomainDevice:
                         self._chk(L.md_dom_set_scale(h, scale))
                 s = g + 1
             else:
+                stuck = 0
                 self.steps_since_build += wlen
                 s += wlen
                 if ends_run:

@@ -341,3 +341,35 @@ def test_snapshot_export_overlaps_the_next_segment():
         assert not np.array_equal(x1, x0)
         with pytest.raises(MdhipError, match="no frame in flight"):
             d.snapshot_end()
+
+
+def test_blown_up_system_does_not_kill_the_process(tmp_path):
+    """Two particles on top of each other: infinite forces, NaN coordinates from the first step on.  The reference keeps
+    stepping and prints NaNs (it checks nothing, SURVEY.md section 8(b) "Errors"); here the planner of md_run measures a
+    NaN displacement rate -- which once ended in a SIGFPE of its integer arithmetic.  Run in a child process: it must end
+    by itself, with NaNs in the state or with an MdhipError, not with a signal."""
+    import subprocess
+    import sys
+    import textwrap
+    code = textwrap.dedent("""
+        import numpy as np, sys
+        sys.path.insert(0, %r)
+        from moleculardynamics.jl_amd import MDDevice, MdhipError
+        from tests.util import lj_system
+        s = lj_system(4096, kT=1.0)
+        s["x"][17] = s["x"][16]
+        try:
+            with MDDevice(3, s["n"], s["box"], 2.5) as dev:
+                dev.set_potential(0, [1.0, 1.0, 2.5])
+                dev.upload(s["x"], s["v"], s["f"], s["img"], s["diam"])
+                for _ in range(3):
+                    dev.run(40, 0.002)
+                x, v, f, img = dev.download()
+            print("finite" if np.isfinite(x).all() else "nan state")
+        except MdhipError as e:
+            print("error:", str(e)[:200])
+    """) % (str(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))),)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    sys.stderr.write(p.stderr[-1500:])
+    assert p.returncode == 0, f"child ended with {p.returncode}: {p.stdout[-300:]}"
+    assert "nan state" in p.stdout or "error:" in p.stdout
