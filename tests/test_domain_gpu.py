@@ -86,6 +86,9 @@ def _launch(nproc, env_extra, port):
     # ... and the overlapped window over the direct exchange: the records go out (stream-ordered stores) while the interior
     # tiles run on their own stream
     (2, 1, "device", "shim-native-prune-big-overlap-direct"),
+    # four ranks: the first ring in which a rank has a peer that is NOT its neighbour -- the sums travel all-to-all, the
+    # records to the two neighbours only, and the skew between non-neighbours is bounded by the sums handshake alone
+    (4, 1, "device", "shim-native-prune-elong"), (4, 0, "device", "shim-native-elong"),
 ])
 def test_slab_decomposition_matches_single_gpu(nproc, nvt, stage, mode):
     # N=8000 -> L=20.7: 2 slabs of 10.4, 3 slabs of 6.9 (>= 2 cells each); kT=2 and dt=0.002 make
@@ -98,7 +101,7 @@ def test_slab_decomposition_matches_single_gpu(nproc, nvt, stage, mode):
            "MDHIP_NO_FUSED_STEP": "1" if mode.endswith("classic") else "0",
            "MDHIP_DOM_OVERLAP": "1" if "overlap" in mode else "0",
            "DOM_POLY": "1" if mode.endswith("poly") else "0", "DOM_ELONG": "1" if mode.endswith("elong") else "0",
-           "DOM_N": "8232" if mode.endswith("elong") else ("27000" if "cfg4" in mode else ("110592" if "big" in mode else "8000")),   # 8232 = 2 * 4116 = 3 * 2744
+           "DOM_N": ("10976" if nproc == 4 else "8232") if mode.endswith("elong") else ("27000" if "cfg4" in mode else ("110592" if "big" in mode else "8000")),   # 8232 = 2 * 4116 = 3 * 2744
            "DOM_BACKEND": "nccl" if mode.startswith("nccl") else "gloo"}
     port = 29511 + nproc + 10 * nvt + (20 if stage else 0) + {"sync": 0, "async": 40, "nccl-sync": 80, "nccl-async": 120,
                                                                 "nccl-native": 160, "nccl-native-prune": 200, "async-prune": 240, "async-prune-poly": 280,
@@ -110,7 +113,8 @@ def test_slab_decomposition_matches_single_gpu(nproc, nvt, stage, mode):
                                                                 "nccl-native-prune-overlap": 840, "shim-native-prune-rccl": 880,
                                                                 "shim-native-rccl": 920, "nccl-native-prune-rccl": 960,
                                                                 "shim-native-prune-split": 1000,
-                                                                "shim-native-prune-big-overlap-direct": 1040}[mode]
+                                                                "shim-native-prune-big-overlap-direct": 1040, "shim-native-prune-elong": 1080,
+                                                                "shim-native-elong": 1120}[mode]
     if "overlap" in mode:
         env["MDHIP_DEBUG"] = "1"
     if "native" in mode:
