@@ -2,8 +2,9 @@
 // x axis per handle).  Particles migrate to the neighbour slabs at list builds; between builds
 // the owners of the particles within rc+skin of a slab face send their coordinates to the
 // neighbour every step, where they refresh the "x-halo" ghost copies.  y and z keep the
-// periodic self-image ghosts of the single-GPU path.  Transport lives outside the library
-// (torch.distributed: RCCL over xGMI on a multi-GPU node).
+// periodic self-image ghosts of the single-GPU path.  Transport: the library's own (an RCCL communicator for list builds
+// and as the fallback; for the steps of a fused window the direct peer exchange further down -- one-sided stores over
+// xGMI into the peers' mailboxes), or the caller's (torch.distributed drives the phase-by-phase entry points).
 #pragma once
 
 #define MD_MIG_REC 14 // x y z sigma | vx vy vz | fx fy fz | imgx imgy imgz | id      (doubles)
