@@ -665,24 +665,34 @@ __global__ void __launch_bounds__(MD_BLOCK)
                        aa.term1, aa.kt, aa.r1, aa.r2, sc, step, finalize, pg, kuw_sh, &comm_state);
 }
 
-// md_dom_comm_init's rehearsal of the direct exchange: one exchange with no records and known sums
-__global__ void __launch_bounds__(MD_BLOCK) k_p2p_hello_put(P2pPut pp, double a)
+// md_dom_comm_init's rehearsal of the direct exchange: one exchange with known sums and a 64-word pattern in each of the two
+// neighbours' record planes (the plane addresses come from the capacities the ranks told each other)
+__global__ void __launch_bounds__(MD_BLOCK) k_p2p_hello_put(P2pPut pp, double a, double *out0, double *out1, double tag0, double tag1)
 {
     if (blockIdx.x == 0) {
         p2p_put_sums(pp, a, 1.0, 0.0, 0.0);
         return;
     }
+    if (threadIdx.x < 64) {
+        p2p_st(out0 + threadIdx.x, tag0 + (double)threadIdx.x);
+        p2p_st(out1 + threadIdx.x, tag1 + (double)threadIdx.x);
+    }
     p2p_records_done(pp, gridDim.x - 1);
 }
-__global__ void __launch_bounds__(MD_BLOCK) k_p2p_hello_get(P2pGet pg, Scalars *sc, double *out4)
+__global__ void __launch_bounds__(MD_BLOCK)
+    k_p2p_hello_get(P2pGet pg, Scalars *sc, double *out4, const double *in0, const double *in1, double want0, double want1)
 {
     __shared__ double kuw_sh[4];
     __shared__ int comm_state;
     int st = p2p_collect(pg, sc, kuw_sh, &comm_state);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
+        int bad = 0;
+        if (st == 0)
+            for (int i = 0; i < 64; ++i) bad += (p2p_ld(in0 + i) != want0 + (double)i) + (p2p_ld(in1 + i) != want1 + (double)i);
         out4[0] = st == 0 ? kuw_sh[0] : -1.0;
         out4[1] = st == 0 ? kuw_sh[1] : -1.0;
         out4[2] = (double)st;
+        out4[3] = (double)bad;
     }
 }
 

@@ -3267,12 +3267,18 @@ static void dom_p2p_setup(md_ctx *ctx)
         q.on = true;
         q.seq = 1;
         k_reset_viol<<<1, 1, 0, st>>>(ctx->scal.p);
-        k_p2p_hello_put<<<2, MD_BLOCK, 0, st>>>(dom_p2p_put_args(ctx, q.seq), (double)(d.rank + 1));
-        k_p2p_hello_get<<<2, MD_BLOCK, 0, st>>>(dom_p2p_get_args(ctx, q.seq, 10ll * 100000000ll), ctx->scal.p, tmp.p);
-        double h[3] = {0, 0, 0};
+        // (what this rank sends left arrives "from the right" at its left neighbour: tag 1000 (sender + 1) + side of arrival)
+        const int left = (d.rank + R - 1) % R, right = (d.rank + 1) % R;
+        k_p2p_hello_put<<<2, MD_BLOCK, 0, st>>>(dom_p2p_put_args(ctx, q.seq), (double)(d.rank + 1), dom_p2p_send_plane(ctx, 0, q.seq),
+                                                dom_p2p_send_plane(ctx, 1, q.seq), 1000.0 * (d.rank + 1) + 100.0,
+                                                1000.0 * (d.rank + 1));
+        k_p2p_hello_get<<<2, MD_BLOCK, 0, st>>>(dom_p2p_get_args(ctx, q.seq, 10ll * 100000000ll), ctx->scal.p, tmp.p,
+                                                dom_p2p_recv_plane(ctx, 0, q.seq), dom_p2p_recv_plane(ctx, 1, q.seq),
+                                                1000.0 * (left + 1), 1000.0 * (right + 1) + 100.0);
+        double h[4] = {0, 0, 0, 0};
         HIPCHK(hipMemcpyAsync(h, tmp.p, sizeof h, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
-        if (h[2] != 0.0 || h[0] != 0.5 * R * (R + 1.0) || h[1] != (double)R) {
+        if (h[2] != 0.0 || h[3] != 0.0 || h[0] != 0.5 * R * (R + 1.0) || h[1] != (double)R) {
             ok = 0;
             why = "the rehearsal exchange did not deliver";
         }
