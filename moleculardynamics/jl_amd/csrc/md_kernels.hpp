@@ -196,23 +196,18 @@ __device__ __forceinline__ bool wrap_general(double &x, double &y, double &z, co
 // exact, sums left to right), x_r + t_r -- the oracle's tric_d2.
 __device__ __forceinline__ void shift_xyz(double &x, double &y, double &z, uint32_t code, const double *L, int tric, const double *A)
 {
-    const uint32_t sx = code & 3u, sy = (code >> 2) & 3u, sz = (code >> 4) & 3u;
-    if (!tric) {
-        if (sx == 1u) x = x + L[0];
-        if (sx == 2u) x = x - L[0];
-        if (sy == 1u) y = y + L[1];
-        if (sy == 2u) y = y - L[1];
-        if (sz == 1u) z = z + L[2];
-        if (sz == 2u) z = z - L[2];
-    } else {
 #pragma clang fp contract(off)
-        const double s0 = sx == 1u ? 1.0 : (sx == 2u ? -1.0 : 0.0);
-        const double s1 = sy == 1u ? 1.0 : (sy == 2u ? -1.0 : 0.0);
-        const double s2 = sz == 1u ? 1.0 : (sz == 2u ? -1.0 : 0.0);
-        x = x + ((s0 * A[0] + s1 * A[1]) + s2 * A[2]);
-        y = y + ((s0 * A[3] + s1 * A[4]) + s2 * A[5]);
-        z = z + ((s0 * A[6] + s1 * A[7]) + s2 * A[8]);
-    }
+    // One formula for both kinds of cell: for a diagonal matrix the two foreign products of every component are exact
+    // zeros, (s0 L + 0) + 0 = s0 L exactly, and x + s0 L is the single rounded addition of the orthorhombic path.
+    (void)L;
+    (void)tric;
+    const uint32_t sx = code & 3u, sy = (code >> 2) & 3u, sz = (code >> 4) & 3u;
+    const double s0 = sx == 1u ? 1.0 : (sx == 2u ? -1.0 : 0.0);
+    const double s1 = sy == 1u ? 1.0 : (sy == 2u ? -1.0 : 0.0);
+    const double s2 = sz == 1u ? 1.0 : (sz == 2u ? -1.0 : 0.0);
+    x = x + ((s0 * A[0] + s1 * A[1]) + s2 * A[2]);
+    y = y + ((s0 * A[3] + s1 * A[4]) + s2 * A[5]);
+    z = z + ((s0 * A[6] + s1 * A[7]) + s2 * A[8]);
 }
 
 // Row entries of tile t live at rows16[wave_tile_base + row_off(r, lane)]: groups of four
