@@ -152,6 +152,27 @@ def forces_brute(x, box, cutoff, pot, diam, want_pairs=False):
     return f, u.value, w.value, npairs
 
 
+def default_threads():
+    """Threads for nthreads <= 0: the cores this process may really use (affinity AND the cgroup's CPU quota), at most 16.
+    OpenMP's own default counts every core of the host: on a box whose share is a quota (the GPU boxes: 16 CPUs of a much
+    larger machine) that oversubscribes it several times over and allocates one private force array per phantom thread --
+    the 4 M-particle parity test spent 14 s per force evaluation that way."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(p))))
+    except Exception:
+        pass
+    if os.environ.get("OMP_NUM_THREADS", "").isdigit():
+        n = min(n, int(os.environ["OMP_NUM_THREADS"]))
+    return max(1, min(n, 16, max(1, max_threads())))
+
+
 def forces_cells(x, box, cutoff, pot, diam, nthreads=0):
     x = _f64(x)
     n, d = x.shape
@@ -160,7 +181,7 @@ def forces_cells(x, box, cutoff, pot, diam, nthreads=0):
     f = np.zeros_like(x)
     u, w = C.c_double(), C.c_double()
     npairs = lib().oracle_forces_cells(d, n, _d(x), _d(box), cutoff, C.byref(pot), _d(diam), _d(f), C.byref(u),
-                                       C.byref(w), nthreads)
+                                       C.byref(w), nthreads if nthreads > 0 else default_threads())
     return f, u.value, w.value, npairs
 
 
@@ -194,7 +215,8 @@ def run(x, img, v, f, diam, box, cutoff, pot, dt, nsteps, ensemble=0, tau=0.1, k
     last = np.zeros(3)
     nout = lib().oracle_run(d, n, _d(x), _i(img), _d(v), _d(f), _d(diam), _d(box), cutoff, C.byref(pot), dt,
                             ensemble, tau, nf, _d(kt), _d(a1), _d(a2), nsteps, frequency,
-                            _d(thermo) if frequency > 0 else None, 1 if use_cells else 0, nthreads, _d(last))
+                            _d(thermo) if frequency > 0 else None, 1 if use_cells else 0,
+                            nthreads if nthreads > 0 else default_threads(), _d(last))
     return dict(x=x, img=img, v=v, f=f, thermo=thermo[:nout], U=last[0], W=last[1], K=last[2])
 
 
