@@ -367,6 +367,34 @@ def test_config3_1m_nvt_end_to_end(oracle):
     assert abs(W - ref["W"]) <= 1e-11 * abs(ref["W"])
 
 
+def test_many_list_cycles_262k_nvt(oracle):
+    """BASELINE configs[1]'s size over several complete list cycles: 262,144 particles, NVT, 240 steps -- four or more list
+    rebuilds and a dozen prune steps, the planner adapting its window lengths -- against oracle.run (which rebuilds its
+    cells every step, as the reference does) with the same thermostat draws.  What the short end-to-end runs cannot show:
+    that nothing drifts from one list generation to the next."""
+    from moleculardynamics.jl_amd import MDDevice, _lib
+    from moleculardynamics.jl_amd.thermostat import draw_bussi
+    n, nsteps, dt, tau, kT = 262144, 240, 0.001, 0.1, 1.4737
+    s = lj_system(n, kT=kT)
+    nf = 3.0 * (n - 1.0)
+    r1, r2 = draw_bussi(nf, np.random.default_rng(99), nsteps)
+    kt = np.full(nsteps, kT)
+    pot = oracle.make_pot(0, LJ)
+    ref = oracle.run(s["x"], s["img"], s["v"], s["f"], s["diam"], s["box"], 2.5, pot, dt, nsteps, ensemble=1, tau=tau,
+                     ktemp=kt, r1=r1, r2=r2, nthreads=0)
+    with MDDevice(3, n, s["box"], 2.5) as d:
+        d.set_potential(0, LJ)
+        d.upload(s["x"], s["v"], s["f"], s["img"], s["diam"])
+        U, W, K = d.run(nsteps, dt, _lib.MD_NVT, tau, nf, kt, r1, r2)
+        x, v, f, img = d.download()
+        st = d.stats()
+    assert st["fused"] == 1 and st["rebuilds"] >= 4 and st["prunes"] >= 10 and st["steps"] == nsteps
+    assert np.array_equal(img, ref["img"])
+    assert np.abs(x - ref["x"]).max() <= 1e-9 and np.abs(v - ref["v"]).max() <= 1e-9
+    _check_forces(f, ref["f"], 1e-9)
+    assert abs(U - ref["U"]) <= 1e-10 * abs(ref["U"]) and abs(K - ref["K"]) <= 1e-11 * abs(ref["K"])
+
+
 def test_nve_energy_drift_matches_oracle_262k(oracle):
     """north_star: "energy drift within CPU-reference tolerance".  40 NVE steps at N=262144 on both sides from the
     same start: the total energy changes by the same amount (the drift is the truncated potential's, not the
