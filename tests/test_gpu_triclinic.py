@@ -108,7 +108,7 @@ def test_sheared_cell_equal_to_a_cubic_lattice():
     a check of the general-cell path that needs no oracle."""
     from moleculardynamics.jl_amd import MDDevice
     from tests.util import lj_system
-    s = lj_system(6000, kT=1.3)
+    s = lj_system(65536, kT=1.3)      # (256 tiles: bricks, tile halos and virtual ghosts in the sheared geometry)
     M = np.array([[1.0, 1.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0]])     # a_2' = a_1 + a_2: a 45-degree shear
     res = []
     for cell in (np.diag(s["box"]), np.diag(s["box"]) @ M):
