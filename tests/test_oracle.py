@@ -303,3 +303,36 @@ def test_general_cell_same_lattice_same_physics(oracle):
     a, b = res
     assert a[2] == b[2] and abs(a[0] - b[0]) < 1e-11 * abs(a[0]) and abs(a[1] - b[1]) < 1e-11 * abs(a[1])
     assert np.abs(a[3] - b[3]).max() < 1e-10 and np.abs(a[4] - b[4]).max() < 1e-10
+
+
+def test_oracle_reproduces_a_nist_lj_state_point(oracle):
+    """An external known answer for the ORACLE's physics (its arithmetic stays unpinned against the reference, which holds no
+    fixture): the NIST Standard Reference Simulation Website's Lennard-Jones benchmark at T* = 0.85, rho* = 0.776
+    (r_c = 3 sigma + long-range corrections): U*/N = -5.5121, p* = 0.0068.  864 particles, NVT (Bussi), 3000 + 9000 steps at
+    dt = 0.005 through oracle_run -- integrate_half!, the linked-cell pair map, integrate_second_half!, bussi! as restated -- with
+    the tail corrections of src/potentials.jl:111-152.  Tolerances: four standard errors of a run this short (0.002 in U, 0.015
+    in p) plus the finite-size and time-step bias; tests/test_gpu_parity.py holds the tighter device-side version."""
+    from moleculardynamics.jl_amd import lattice_positions, initialize_velocities
+    from moleculardynamics.jl_amd.thermostat import draw_bussi
+    n, rho, T, rc, dt = 864, 0.776, 0.85, 3.0, 0.005
+    nequil, nprod, every = 3000, 9000, 10
+    L = (n / rho) ** (1.0 / 3.0)
+    box = np.full(3, L)
+    x = lattice_positions(n, box, 3, np.random.default_rng(1))
+    v = initialize_velocities(T, np.random.default_rng(2), n, 3)
+    nf = 3.0 * (n - 1.0)
+    nsteps = nequil + nprod
+    r1, r2 = draw_bussi(nf, np.random.default_rng(3), nsteps)
+    pot = oracle.make_pot(0, [1.0, 1.0, rc])
+    f0, _, _, _ = oracle.forces_cells(x, box, rc, pot, np.ones(n), nthreads=4)
+    res = oracle.run(x, np.zeros((n, 3), np.int32), v, f0, np.ones(n), box, rc, pot, dt, nsteps, ensemble=1, tau=0.1,
+                     ktemp=np.full(nsteps, T), r1=r1, r2=r2, frequency=every, nthreads=4)
+    th = res["thermo"]
+    th = th[th[:, 0] >= nequil]
+    u_lrc = (8.0 / 3.0) * np.pi * rho * ((1.0 / 3.0) * rc ** -9 - rc ** -3)
+    p_lrc = (16.0 / 3.0) * np.pi * rho ** 2 * ((2.0 / 3.0) * rc ** -9 - rc ** -3)
+    u = float(np.mean(th[:, 1] / n + u_lrc))
+    p = float(np.mean(rho * th[:, 2] + th[:, 3] / (3.0 * L ** 3) + p_lrc))
+    assert abs(np.mean(th[:, 2]) - T) <= 0.01
+    assert abs(u + 5.5121) <= 0.012, u
+    assert abs(p - 0.0068) <= 0.07, p
