@@ -857,3 +857,35 @@ def test_lj_fluid_against_the_nist_reference_table(rho, u_nist, p_nist):
     u_mean, p_mean = float(np.mean(us)), float(np.mean(ps))
     assert abs(u_mean - u_nist) <= 0.005, (u_mean, u_nist)
     assert abs(p_mean - p_nist) <= 0.025, (p_mean, p_nist)
+
+
+@pytest.mark.parametrize("rho", [0.3, 0.5, 0.7])
+def test_pseudo_hard_spheres_against_carnahan_starling(rho):
+    """BASELINE configs[0]'s potential against an answer from outside: PseudoHS (src/potentials.jl:5-29, the 50-49 Mie
+    potential built to reproduce hard spheres at T* = 1.4737) must give the hard-sphere equation of state.  Compressibility
+    factor Z = P / (rho kT) from the virial of an NVT run (4000 particles, 10 000 + 30 000 steps, dt = 0.0005, tau = 100 dt as
+    README.md:33) against Carnahan-Starling, Z = (1 + f + f^2 - f^3) / (1 - f)^3, f = pi rho / 6, itself good to a few 1e-3
+    of the hard-sphere fluid: measured ratio 0.9996 / 0.9999 / 1.0016 at rho = 0.3 / 0.5 / 0.7 (scripts/probe/phs_eos.py);
+    the test allows 1 %."""
+    from moleculardynamics.jl_amd import MDDevice, _lib, lattice_positions, initialize_velocities
+    from moleculardynamics.jl_amd.thermostat import draw_bussi
+    n, T, dt, every, nequil, nprod = 4000, 1.4737, 0.0005, 20, 10000, 30000
+    L = (n / rho) ** (1.0 / 3.0)
+    box = np.full(3, L)
+    x = lattice_positions(n, box, 3, np.random.default_rng(1))
+    v = initialize_velocities(T, np.random.default_rng(2), n, 3)
+    nf = 3.0 * (n - 1.0)
+    rng = np.random.default_rng(3)
+    zs = []
+    with MDDevice(3, n, box, 1.5) as dev:
+        dev.set_potential(_lib.MD_POT_PSEUDOHS, [50.0])
+        dev.upload(x, v, np.zeros_like(x), np.zeros((n, 3), np.int32), np.ones(n))
+        r1, r2 = draw_bussi(nf, rng, nequil)
+        dev.run(nequil, dt, _lib.MD_NVT, 100 * dt, nf, np.full(nequil, T), r1, r2)
+        for _ in range(nprod // every):
+            r1, r2 = draw_bussi(nf, rng, every)
+            U, W, K = dev.run(every, dt, _lib.MD_NVT, 100 * dt, nf, np.full(every, T), r1, r2)
+            zs.append((rho * (2.0 * K / nf) + W / (3.0 * L ** 3)) / (rho * T))
+    f = np.pi * rho / 6.0
+    z_cs = (1.0 + f + f * f - f ** 3) / (1.0 - f) ** 3
+    assert abs(np.mean(zs) / z_cs - 1.0) <= 0.01, (float(np.mean(zs)), z_cs)
