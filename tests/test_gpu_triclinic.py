@@ -194,3 +194,40 @@ def test_upload_outside_a_triclinic_cell_wraps_like_wrap_to_box():
     assert fr.min() > -1e-13 and fr.max() < 1.0 + 1e-13
     assert np.array_equal(img1 - img_in, shift)
     assert np.abs(x1 - x).max() <= 1e-13 * 60.0
+
+
+def test_triclinic_lj_fluid_reproduces_the_nist_state_point():
+    """The external known answer of tests/test_gpu_parity.py (NIST reference table, LJ r_c = 3 sigma + tail corrections,
+    T* = 0.85, rho* = 0.820: U*/N = -5.7947, p* = 0.5535) in a TRICLINIC cell of the same volume (tilt factors 0.3, 0.2, -0.25 of
+    the edge): the thermodynamics of a homogeneous fluid cannot depend on the shape of the periodic cell, so the general-cell path
+    -- fractional cells, lattice-vector ghosts, the general wrap -- is tied to a published number without any oracle."""
+    from moleculardynamics.jl_amd import MDDevice, _lib, initialize_velocities
+    from moleculardynamics.jl_amd.thermostat import draw_bussi
+    n, rho, T, rc, dt, every, nequil, nprod = 4000, 0.820, 0.85, 3.0, 0.004, 20, 15000, 40000
+    L = (n / rho) ** (1.0 / 3.0)
+    U = np.array([[L, 0.3 * L, 0.2 * L], [0.0, L, -0.25 * L], [0.0, 0.0, L]])
+    assert abs(np.linalg.det(U) - L ** 3) < 1e-9 * L ** 3
+    rng = np.random.default_rng(11)
+    m = 16
+    g = np.stack(np.meshgrid(*[np.arange(m)] * 3, indexing="ij"), -1).reshape(-1, 3)
+    g = g[rng.permutation(len(g))[:n]].astype(float)
+    x = ((g + 0.5) / m) @ U.T + rng.uniform(-0.03, 0.03, (n, 3))
+    v = initialize_velocities(T, np.random.default_rng(2), n, 3)
+    nf = 3.0 * (n - 1.0)
+    u_lrc = (8.0 / 3.0) * np.pi * rho * ((1.0 / 3.0) * rc ** -9 - rc ** -3)
+    p_lrc = (16.0 / 3.0) * np.pi * rho ** 2 * ((2.0 / 3.0) * rc ** -9 - rc ** -3)
+    us, ps = [], []
+    with MDDevice(3, n, U, rc) as dev:
+        dev.set_potential(_lib.MD_POT_LJ, [1.0, 1.0, rc])
+        dev.upload(x, v, np.zeros_like(x), np.zeros((n, 3), np.int32), np.ones(n))
+        r1, r2 = draw_bussi(nf, rng, nequil)
+        dev.run(nequil, dt, _lib.MD_NVT, 0.1, nf, np.full(nequil, T), r1, r2)
+        for _ in range(nprod // every):
+            r1, r2 = draw_bussi(nf, rng, every)
+            Ue, W, K = dev.run(every, dt, _lib.MD_NVT, 0.1, nf, np.full(every, T), r1, r2)
+            us.append(Ue / n + u_lrc)
+            ps.append(rho * (2.0 * K / nf) + W / (3.0 * L ** 3) + p_lrc)
+        xf, _, _, img = dev.download()
+    assert np.abs(img).max() >= 1      # (a liquid: particles did cross the faces of the cell)
+    assert abs(np.mean(us) + 5.7947) <= 0.005, float(np.mean(us))
+    assert abs(np.mean(ps) - 0.55355) <= 0.025, float(np.mean(ps))
